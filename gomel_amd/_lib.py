@@ -1,0 +1,96 @@
+"""ctypes binding of include/gomel_hip.h.  There is no CPU fallback: if libgomel_hip.so is missing or a call
+fails, this raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgomel_hip.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_size_p = ctypes.POINTER(ctypes.c_size_t)
+c_u64_p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class GomelConfig(ctypes.Structure):
+    """struct gomel_config (mirrors `type Mel`, mel/mel.go:10-27)."""
+    _fields_ = [("num_mels", ctypes.c_int32), ("window", ctypes.c_int32), ("resolut", ctypes.c_int32),
+                ("griffin_lim_iterations", ctypes.c_int32), ("mel_fmin", ctypes.c_double), ("mel_fmax", ctypes.c_double),
+                ("tune_mul", ctypes.c_double), ("tune_add", ctypes.c_double), ("device", ctypes.c_int32),
+                ("hann_periodic", ctypes.c_int32)]
+
+
+class GomelTiming(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_float), ("iter_ms", ctypes.c_float), ("iter_launches", ctypes.c_int32),
+                ("fast_path", ctypes.c_int32), ("frames", ctypes.c_int64)]
+
+
+# every symbol include/gomel_hip.h declares: (restype, argtypes)
+_vp = ctypes.c_void_p
+_cfg_p = ctypes.POINTER(GomelConfig)
+SYMBOLS = {
+    "gomel_default_config": (ctypes.c_int, [_cfg_p]),
+    "gomel_create": (ctypes.c_int, [_cfg_p, ctypes.POINTER(_vp)]),
+    "gomel_create_from_tables": (ctypes.c_int, [_cfg_p, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "gomel_tables_bytes": (ctypes.c_size_t, [_vp]),
+    "gomel_tables_export": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "gomel_set_window": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t]),
+    "gomel_get_window": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t]),
+    "gomel_destroy": (ctypes.c_int, [_vp]),
+    "gomel_out_len": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
+    "gomel_from_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_uint64, c_double_p,
+                                      ctypes.c_size_t, c_size_p]),
+    "gomel_from_mel_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p,
+                                            ctypes.POINTER(c_double_p), c_u64_p, ctypes.POINTER(c_double_p), c_size_p]),
+    "gomel_batch_create": (ctypes.c_int, [_vp, ctypes.c_size_t, c_size_p, ctypes.POINTER(_vp)]),
+    "gomel_batch_upload": (ctypes.c_int, [_vp, ctypes.POINTER(c_double_p), ctypes.POINTER(c_double_p), c_u64_p]),
+    "gomel_batch_run": (ctypes.c_int, [_vp]),
+    "gomel_batch_run_timed": (ctypes.c_int, [_vp, ctypes.POINTER(GomelTiming)]),
+    "gomel_batch_sync": (ctypes.c_int, [_vp]),
+    "gomel_batch_download": (ctypes.c_int, [_vp, ctypes.POINTER(c_double_p), c_size_p]),
+    "gomel_batch_destroy": (ctypes.c_int, [_vp]),
+    "gomel_set_path": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "gomel_to_mel_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
+    "gomel_to_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
+    "gomel_pad_len": (ctypes.c_size_t, [ctypes.c_size_t, ctypes.c_int32]),
+    "gomel_is_padded": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32]),
+    "gomel_rfft_frames": (ctypes.c_int, [_vp, c_float_p, ctypes.c_size_t, c_float_p]),
+    "gomel_irfft_frames": (ctypes.c_int, [_vp, c_float_p, ctypes.c_size_t, c_float_p]),
+    "gomel_target_magnitudes": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_float_p]),
+    "gomel_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "gomel_last_hip_error": (ctypes.c_int, []),
+    "gomel_abi_version": (ctypes.c_int, []),
+    "gomel_device_count": (ctypes.c_int, []),
+    "gomel_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+}
+
+_lib = None
+
+
+class GomelError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().gomel_strerror(status).decode()
+        if status == 8:
+            msg += " [hipError_t %d]" % lib().gomel_last_hip_error()
+        super().__init__("%s: %s (status %d)" % (where, msg, status))
+
+
+def lib():
+    """Load libgomel_hip.so (built in-tree by gomel_amd.build).  Raises if it is absent: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("gomel_amd: %s not found -- run `python -m gomel_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, where):
+    if status != 0:
+        raise GomelError(status, where)

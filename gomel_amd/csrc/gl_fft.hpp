@@ -1,0 +1,298 @@
+// gl_fft.hpp -- register/LDS real-FFT core for the Griffin-Lim iteration on gfx950 (CDNA4, wave64).
+//
+// Replaces, per frame, go-dsp's fft.FFTReal and fft.IFFT as the reference calls them (mel/mel.go:95,116) and the
+// per-bin Abs/Phase/Rect + conjugate fill between them (mel/mel.go:98-108).
+//
+// Design (not a translation of the reference's complex128 radix-2 loops):
+//  * An N-point real frame is packed as C = N/2 complex points z[n] = x[2n] + i x[2n+1]; one "stream" of
+//    T = C/16 lanes owns a frame, 16 complex points per lane, so x / window / overlap-add live in registers
+//    at pair index n = t + T*j (lane t, register j).
+//  * Three in-register passes R1 x R2 x R3 (16x16x8, 16x8x8, 8x8x8 for N = 4096, 2048, 1024) with two LDS
+//    exchanges (layouts A and B below, padded so the b64 reads of every pass are bank-conflict free).
+//  * The last pass is always radix-8 and each lane runs the two mirrored butterflies b and B3-b, so the bins
+//    k and C-k that the real-FFT split needs meet in ONE lane's registers: the split, the magnitude clamp /
+//    phase keep (Y = M X/|X|), and the merge for the inverse all happen in registers with no LDS traffic.
+//  * The inverse runs the same three passes transposed (R3, R2, R1) with conjugated twiddles, through the same
+//    LDS layouts, and lands back in the n = t + T*j register layout ready for the synthesis window and OLA.
+//  * Twiddles come from small tables (TW1: W_C^{t1 q1}, TW2: W_{C1}^{t2 q2}, WN: W_N^k) held in LDS or L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace glfft {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <class V> struct ScalarOf;
+template <> struct ScalarOf<v2f> { typedef float type; };
+template <> struct ScalarOf<v2d> { typedef double type; };
+
+#define GL_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------- geometry
+template <int N_> struct Geo;
+template <int N_, int R1_, int R2_> struct GeoBase {
+    static constexpr int N = N_;          // real frame length (Resolut)
+    static constexpr int C = N_ / 2;      // complex FFT length
+    static constexpr int P = 16;          // complex points per lane
+    static constexpr int T = C / P;       // lanes per frame stream
+    static constexpr int R1 = R1_, R2 = R2_, R3 = 8;
+    static_assert(R1 * R2 * R3 == C, "radix split");
+    static constexpr int C1 = C / R1;     // length of the sub-FFTs after pass 1
+    static constexpr int B3 = C / R3;     // number of pass-3 butterflies; Z index k = b + B3*r
+    static constexpr int NB1 = P / R1;    // pass-1 butterflies per lane
+    static constexpr int NB2 = P / R2;    // pass-2 butterflies per lane
+    static constexpr int SA = C1 + 32 / R1;  // row stride of exchange layout A (b64 slots)
+    static constexpr int SB = B3 + R1;       // row stride of exchange layout B
+    static constexpr int SLOTS_A = R1 * SA, SLOTS_B = R3 * SB;
+    static constexpr int LDS_SLOTS = SLOTS_A > SLOTS_B ? SLOTS_A : SLOTS_B;  // v2f slots per stream
+    static constexpr int TW1_N = R1 * C1;  // == C entries, index q1*C1 + t1
+    static constexpr int TW2_N = R2 * R3;  // index q2*8 + t2
+};
+template <> struct Geo<4096> : GeoBase<4096, 16, 16> {};
+template <> struct Geo<2048> : GeoBase<2048, 16, 8> {};
+template <> struct Geo<1024> : GeoBase<1024, 8, 8> {};
+
+// Device-side view of the twiddle tables (global memory or LDS; the code is the same).
+template <class V> struct Twiddles {
+    const V* tw1;  // [R1][C1]  W_C^{t1 q1}
+    const V* tw2;  // [R2][8]   W_{C1}^{t2 q2}
+    const V* wn;   // [C]       W_N^k
+};
+
+// ---------------------------------------------------------------------------------------------- complex helpers
+template <class V> GL_DEV V cmul(V a, V b) { return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+template <class V> GL_DEV V cmulc(V a, V b) { return V{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
+template <bool INV, class V> GL_DEV V mul_mi(V a) { return INV ? V{-a.y, a.x} : V{a.y, -a.x}; }  // * (-i) fwd, (+i) inv
+// a * (c - i s) forward, a * (c + i s) inverse
+template <bool INV, class V> GL_DEV V twc(V a, double c_, double s_) {
+    typedef typename ScalarOf<V>::type S;
+    const S c = (S)c_, s = (S)s_;
+    return INV ? V{a.x * c - a.y * s, a.y * c + a.x * s} : V{a.x * c + a.y * s, a.y * c - a.x * s};
+}
+
+constexpr double kS2 = 0.70710678118654752440;  // sqrt(1/2)
+constexpr double kC1 = 0.92387953251128675613;  // cos(pi/8)
+constexpr double kS1 = 0.38268343236508977173;  // sin(pi/8)
+
+template <bool INV, class V> GL_DEV void dft4(V& a0, V& a1, V& a2, V& a3) {
+    V s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = mul_mi<INV>(a1 - a3);
+    a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+}
+
+// In-place DFT of R registers at stride S in v[]; output q lands in v[q*S] (natural order).
+template <bool INV, int S, class V> GL_DEV void dft8(V* v) {
+    V u0[4], u1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { u0[j] = v[j * S] + v[(j + 4) * S]; u1[j] = v[j * S] - v[(j + 4) * S]; }
+    u1[1] = twc<INV>(u1[1], kS2, kS2);
+    u1[2] = mul_mi<INV>(u1[2]);
+    u1[3] = twc<INV>(u1[3], -kS2, kS2);
+    dft4<INV>(u0[0], u0[1], u0[2], u0[3]);
+    dft4<INV>(u1[0], u1[1], u1[2], u1[3]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { v[(2 * r) * S] = u0[r]; v[(2 * r + 1) * S] = u1[r]; }
+}
+
+template <bool INV, int S, class V> GL_DEV void dft16(V* v) {
+    V u[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u[j][0] = v[j * S]; u[j][1] = v[(j + 4) * S]; u[j][2] = v[(j + 8) * S]; u[j][3] = v[(j + 12) * S];
+        dft4<INV>(u[j][0], u[j][1], u[j][2], u[j][3]);
+    }
+    // u[j][p] *= W16^{j p}
+    u[1][1] = twc<INV>(u[1][1], kC1, kS1);
+    u[1][2] = twc<INV>(u[1][2], kS2, kS2);
+    u[1][3] = twc<INV>(u[1][3], kS1, kC1);
+    u[2][1] = twc<INV>(u[2][1], kS2, kS2);
+    u[2][2] = mul_mi<INV>(u[2][2]);
+    u[2][3] = twc<INV>(u[2][3], -kS2, kS2);
+    u[3][1] = twc<INV>(u[3][1], kS1, kC1);
+    u[3][2] = twc<INV>(u[3][2], -kS2, kS2);
+    u[3][3] = twc<INV>(u[3][3], -kC1, -kS1);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        dft4<INV>(u[0][p], u[1][p], u[2][p], u[3][p]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[(p + 4 * r) * S] = u[r][p];
+    }
+}
+
+template <bool INV, int R, int S, class V> GL_DEV void dftR(V* v) {
+    if constexpr (R == 16) dft16<INV, S>(v); else dft8<INV, S>(v);
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+// In: v[j] = z[t + T*j].  Out: v[0..7] = Z[bA + B3*r], v[8..15] = Z[bB + B3*r] with bA = t, bB = (t ? B3 - t : B3/2).
+// `lds` is this stream's exchange area (G::LDS_SLOTS slots).  SYNC() is a barrier covering the stream's lanes.
+template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+    // ---- pass 1: NB1 radix-R1 butterflies; butterfly u holds registers j = u + NB1*m, t1 = t + T*u
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++) dftR<false, G::R1, G::NB1>(&v[u]);
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++) {
+        const int t1 = t + G::T * u;
+#pragma unroll
+        for (int q = 0; q < G::R1; q++) {
+            V val = v[u + G::NB1 * q];
+            if (q) val = cmul(val, tw.tw1[q * G::C1 + t1]);
+            lds[q * G::SA + t1] = val;
+        }
+    }
+    sync();
+    // ---- pass 2: NB2 radix-R2 butterflies beta = t + T*u2 -> (q1 = beta % R1, t2 = beta / R1)
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) {
+        const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
+#pragma unroll
+        for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * G::SA + t2 + 8 * m];
+    }
+    sync();
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) {
+        const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
+        dftR<false, G::R2, 1>(&v[u * G::R2]);
+#pragma unroll
+        for (int q = 0; q < G::R2; q++) {
+            V val = v[u * G::R2 + q];
+            if (q) val = cmul(val, tw.tw2[q * 8 + t2]);
+            lds[t2 * G::SB + q1 + G::R1 * q] = val;
+        }
+    }
+    sync();
+    // ---- pass 3: the mirrored radix-8 butterflies bA, bB
+    const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { v[r] = lds[r * G::SB + bA]; v[8 + r] = lds[r * G::SB + bB]; }
+    sync();
+    dft8<false, 1>(&v[0]);
+    dft8<false, 1>(&v[8]);
+}
+
+// ---------------------------------------------------------------------------------------------- inverse
+// In: v[0..7] = Z'[bA + B3*r], v[8..15] = Z'[bB + B3*r].  Out: v[j] = sum_k Z'[k] e^{+2 pi i nk/C}, n = t + T*j
+// (unnormalised; the 1/N of fft.IFFT is folded into the target magnitudes).
+template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+    const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
+    dft8<true, 1>(&v[0]);
+    dft8<true, 1>(&v[8]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) { lds[r * G::SB + bA] = v[r]; lds[r * G::SB + bB] = v[8 + r]; }
+    sync();
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) {
+        const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
+#pragma unroll
+        for (int q = 0; q < G::R2; q++) {
+            V val = lds[t2 * G::SB + q1 + G::R1 * q];
+            if (q) val = cmulc(val, tw.tw2[q * 8 + t2]);
+            v[u * G::R2 + q] = val;
+        }
+    }
+    sync();
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) {
+        const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
+        dftR<true, G::R2, 1>(&v[u * G::R2]);
+#pragma unroll
+        for (int m = 0; m < G::R2; m++) lds[q1 * G::SA + t2 + 8 * m] = v[u * G::R2 + m];
+    }
+    sync();
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++) {
+        const int t1 = t + G::T * u;
+#pragma unroll
+        for (int q = 0; q < G::R1; q++) {
+            V val = lds[q * G::SA + t1];
+            if (q) val = cmulc(val, tw.tw1[q * G::C1 + t1]);
+            v[u + G::NB1 * q] = val;
+        }
+    }
+    sync();
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++) dftR<true, G::R1, G::NB1>(&v[u]);
+}
+
+// ---------------------------------------------------------------------------------------------- spectral step
+// Lane t's eight bin pairs after fft_forward: slot s pairs bin kA = t + B3*s (v[s]) with C - kA (v[15 - s]).
+// Lane 0 is special (its butterflies are self-mirrored); it is permuted into the same slot shape:
+//   slots 1..3 -> (VA[s], VA[8-s]), slots 4..7 -> (VB[s-4], VB[11-s]), slot 0 -> the self-paired bin C/2 (VA[4], VA[4]);
+// DC and Nyquist (both in VA[0]) are handled apart.
+template <class G> GL_DEV int slot_bin(int t, int s) {
+    if (t) return t + G::B3 * s;
+    return s == 0 ? G::C / 2 : (s < 4 ? G::B3 * s : G::B3 / 2 + G::B3 * (s - 4));
+}
+
+template <class G> GL_DEV void lane0_permute(v2f (&v)[16], bool is0) {
+    // (PA | PB) <- (VA | VB):  PA = [VA4 VA1 VA2 VA3 VB0 VB1 VB2 VB3], PB = [VB4 VB5 VB6 VB7 VA5 VA6 VA7 VA4]
+    if (is0) {
+        v2f a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[i] = v[i]; b[i] = v[8 + i]; }
+        v[0] = a[4]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        v[8] = b[4]; v[9] = b[5]; v[10] = b[6]; v[11] = b[7]; v[12] = a[5]; v[13] = a[6]; v[14] = a[7]; v[15] = a[4];
+    }
+}
+template <class G> GL_DEV void lane0_unpermute(v2f (&v)[16], bool is0, v2f dc) {
+    if (is0) {
+        v2f pa[8], pb[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { pa[i] = v[i]; pb[i] = v[8 + i]; }
+        v[0] = dc; v[4] = pa[0]; v[5] = pb[4]; v[6] = pb[5]; v[7] = pb[6];
+        v[8] = pa[4]; v[9] = pa[5]; v[10] = pa[6]; v[11] = pa[7]; v[12] = pb[0]; v[13] = pb[1]; v[14] = pb[2]; v[15] = pb[3];
+    }
+}
+
+// unit phasor of X with the reference's zero rule: cmplx.Phase(0) = 0 -> Rect(M, 0) = M (mel/mel.go:100-101)
+GL_DEV v2f unit_phase(v2f x) {
+    float p = x.x * x.x + x.y * x.y;
+    float r = __builtin_amdgcn_rsqf(p);
+    // one Newton step: v_rsq_f32 is ~1 ulp, keep the phasor at fp32 accuracy
+    r = r * (1.5f - 0.5f * p * r * r);
+    return p > 0.f ? v2f{x.x * r, x.y * r} : v2f{1.f, 0.f};
+}
+
+// Real-FFT split -> X[k], X[C-k]; Y = Ms * X/|X|; merge -> Z'[k], Z'[C-k].  ma/mb are the (1/N-scaled) target
+// magnitudes of bins k and C-k, w = W_N^k.  a = Z[k], b = Z[C-k] on entry; Z'[k], Z'[C-k] on exit.
+GL_DEV void clamp_pair(v2f& a, v2f& b, v2f w, float ma, float mb) {
+    v2f bc = v2f{b.x, -b.y};
+    v2f p = a + bc;                      // 2 E_k
+    v2f d = a - bc;                      // 2 i O_k
+    v2f q = cmul(w, v2f{d.y, -d.x});     // 2 w O_k
+    v2f xk = p + q;                      // 2 X[k]
+    v2f xc = p - q;                      // 2 conj(X[C-k])
+    v2f u = unit_phase(xk) * ma;                    // Y[k]
+    v2f vv = unit_phase(xc) * mb;                   // conj(Y[C-k])  (conj of a unit phasor times a real)
+    v2f e = u + vv;                      // 2 E'
+    v2f o = cmulc(u - vv, w);            // 2 O' = conj(w) (U - V)
+    a = v2f{e.x - o.y, e.y + o.x};       // E' + i O'
+    b = v2f{e.x + o.y, o.x - e.y};       // conj(E' - i O')
+}
+
+// The whole spectral step on a lane's 16 registers.  mag points at this frame's row of N/2 scaled magnitudes,
+// nyq is the scaled magnitude of bin N/2.  (mel/mel.go:98-108 in the real-FFT form, SURVEY Appendix A.)
+template <class G> GL_DEV void spectral_step(v2f (&v)[16], int t, const float* __restrict__ mag, float nyq, const v2f* __restrict__ wn) {
+    const bool is0 = (t == 0);
+    float ma[8], mb[8];
+    v2f w[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        ma[s] = mag[k]; mb[s] = mag[G::C - k]; w[s] = wn[k];
+    }
+    v2f dc = v[0];
+    lane0_permute<G>(v, is0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) clamp_pair(v[s], v[15 - s], w[s], ma[s], mb[s]);
+    if (is0) {
+        // DC and Nyquist: X[0] = Re+Im, X[N/2] = Re-Im (real); Y = +-M; Z'[0] = (Y0+Yn) + i (Y0-Yn)
+        float x0 = dc.x + dc.y, xn = dc.x - dc.y;
+        float y0 = x0 < 0.f ? -mag[0] : mag[0];
+        float yn = xn < 0.f ? -nyq : nyq;
+        dc = v2f{y0 + yn, y0 - yn};
+    }
+    lane0_unpermute<G>(v, is0, dc);
+}
+
+}  // namespace glfft

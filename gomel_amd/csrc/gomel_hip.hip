@@ -1,0 +1,859 @@
+// gomel_hip.hip -- libgomel_hip.so: kernels + C ABI (include/gomel_hip.h) for gomel's FromMel / ToMel path on
+// MI355X (gfx950).  See DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Reference steps replaced (file:line relative to the reference repository):
+//   k_mel_to_mag      spectral_denormalize mel/impl.go:421-427 + undomel :347-384 + undospectrum :386-408
+//   k_init_x          random init mel/mel.go:80-83 (explicit x0 or documented splitmix64 generator)
+//   k_gl_frames       one Griffin-Lim iteration per frame, mel/mel.go:87-121 (generic hop)
+//   k_ola             overlap-add mel/mel.go:112-125,135 (generic hop)
+//   k_gl_fused        the same iteration fused over runs of consecutive frames (hop % (N/8) == 0), registers as OLA
+//   k_finalize        float -> double output (mel/mel.go:138)
+//   k_stft_mag, k_domel_log   ToMel mel/mel.go:46-74, domel mel/impl.go:310-345, spectral_normalize :410-419
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/gomel_hip.h"
+#include "gl_fft.hpp"
+
+using namespace glfft;
+
+// =============================================================================================== device tables
+struct BinRow {  // one linear bin of undomel (or one mel band of domel): data-independent index math, built in fp64 on host
+    int32_t lo, hi;
+    int32_t mode;  // 0 copy band lo; 1 two-tap lo,hi with modlo; 2 sum lo..hi-1 divided by div
+    int32_t pad_;
+    double modlo, div;
+};
+
+struct DevTables {
+    const float* window;   // [N]
+    const v2f* tw1;        // fp32 twiddles (Griffin-Lim)
+    const v2f* tw2;
+    const v2f* wn;
+    const v2d* tw1d;       // fp64 twiddles (ToMel)
+    const v2d* tw2d;
+    const v2d* wnd;
+    const double* windowd; // [N]
+    const BinRow* undo;    // [N/2]
+    const BinRow* dom;     // [K]
+};
+
+GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
+    if (r.mode == 0) return e[r.lo];
+    if (r.mode == 1) return e[r.lo] * (1 - r.modlo) + e[r.hi] * r.modlo;
+    double tot = 0;
+    for (int k = r.lo; k < r.hi; k++) tot += e[k];
+    return tot / r.div;
+}
+
+// =============================================================================================== K1: log-mel -> target magnitudes
+// One block per frame.  mag[f][k] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from
+// channel 1 at bin N/2-1 (the only survivor of channel 1).  fp64 arithmetic, fp32 result.
+__global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
+                                                    float* __restrict__ mag, float* __restrict__ nyq, int K, int H,
+                                                    double tune_add, double tune_mul, double inv_n) {
+    extern __shared__ double e_sh[];  // [2][K]
+    const int64_t f = blockIdx.x;
+    const double* m = mel + f * (int64_t)K * 2;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        e_sh[k] = exp(m[2 * k]);
+        e_sh[K + k] = exp(m[2 * k + 1]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const BinRow r = undo[i];
+        double v0 = (apply_row(r, e_sh) - tune_add) / tune_mul;
+        mag[f * H + i] = (float)(fabs(v0) * inv_n);
+        if (i == H - 1) {
+            double v1 = (apply_row(r, e_sh + K) - tune_add) / tune_mul;
+            nyq[f] = (float)(fabs(v1) * inv_n);
+        }
+    }
+}
+
+// =============================================================================================== K3: initial signal
+GL_DEV double splitmix_u01(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct UttDesc {  // one utterance of a batch
+    int64_t xoff;     // offset of its signal in the x / out buffers (samples)
+    int64_t fbase;    // index of its first frame in the frame-major buffers
+    int32_t frames;
+    int32_t has_x0;
+    int64_t len;      // L = N + (F-1) hop
+    uint64_t seed;
+};
+
+template <class OutT>
+__global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, const double* __restrict__ x0, OutT* __restrict__ x) {
+    const UttDesc u = utts[blockIdx.y];
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+        double v = u.has_x0 ? x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
+        x[u.xoff + n] = (OutT)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, double* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (double)x[i];
+}
+
+// =============================================================================================== generic path: frames kernel
+// WG = 128 lanes = 128/T frame streams.  Each stream: gather frame * Hann -> rFFT -> clamp -> irFFT -> * Hann -> yw[frame][N].
+template <int N>
+__global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, const int64_t* __restrict__ frame_xoff,
+                                                   const float* __restrict__ mag, const float* __restrict__ nyq,
+                                                   float* __restrict__ yw, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;  // keep the lanes in the barriers; results are dropped
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
+    auto sync = [] { __syncthreads(); };
+
+    const v2f* xs = reinterpret_cast<const v2f*>(x + frame_xoff[frame]);  // hop and offsets are even: 8-byte aligned
+    const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
+    v2f v[16], w[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { w[j] = w2[t + G::T * j]; v[j] = xs[t + G::T * j] * w[j]; }
+    fft_forward<G>(v, my, t, tw, sync);
+    spectral_step<G>(v, t, mag + frame * G::C, nyq[frame], tb.wn);
+    fft_inverse<G>(v, my, t, tw, sync);
+    if (live) {
+        v2f* ys = reinterpret_cast<v2f*>(yw + frame * N);
+#pragma unroll
+        for (int j = 0; j < 16; j++) ys[t + G::T * j] = v[j] * w[j];
+    }
+}
+
+// x'[n] = sum over the frames covering n of yw[k][n - k*hop], in frame order (mel/mel.go:115-125).
+__global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, const float* __restrict__ yw, float* __restrict__ xn,
+                                             int N, int hop) {
+    const UttDesc u = utts[blockIdx.y];
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
+        int64_t k1 = n / hop;
+        if (k1 > u.frames - 1) k1 = u.frames - 1;
+        float acc = 0.f;
+        for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
+        xn[u.xoff + n] = acc;
+    }
+}
+
+// =============================================================================================== test hooks: plain rfft / irfft
+template <int N>
+__global__ __launch_bounds__(128) void k_rfft(const float* __restrict__ frames, float* __restrict__ spec, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
+    auto sync = [] { __syncthreads(); };
+    const v2f* xs = reinterpret_cast<const v2f*>(frames + frame * N);
+    v2f v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j];
+    fft_forward<G>(v, my, t, tw, sync);
+    if (!live) return;
+    v2f* out = reinterpret_cast<v2f*>(spec + frame * (N + 2));
+    const bool is0 = (t == 0);
+    v2f dc = v[0];
+    lane0_permute<G>(v, is0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        v2f a = v[s], b = v[15 - s], wk = tb.wn[k];
+        v2f bc = v2f{b.x, -b.y};
+        v2f p = a + bc, d = a - bc;
+        v2f q = cmul(wk, v2f{d.y, -d.x});
+        v2f xk = (p + q) * 0.5f, xc = (p - q) * 0.5f;
+        out[k] = xk;
+        out[G::C - k] = v2f{xc.x, -xc.y};
+    }
+    if (is0) { out[0] = v2f{dc.x + dc.y, 0.f}; out[G::C] = v2f{dc.x - dc.y, 0.f}; }
+}
+
+template <int N>
+__global__ __launch_bounds__(128) void k_irfft(const float* __restrict__ spec, float* __restrict__ frames, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
+    auto sync = [] { __syncthreads(); };
+    const v2f* in = reinterpret_cast<const v2f*>(spec + frame * (N + 2));
+    const bool is0 = (t == 0);
+    const float sc = 1.0f / (float)N;
+    v2f v[16];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        v2f u = in[k] * sc, y2 = in[G::C - k] * sc, wk = tb.wn[k];
+        v2f vv = v2f{y2.x, -y2.y};
+        v2f e = u + vv, o = cmulc(u - vv, wk);
+        v[s] = v2f{e.x - o.y, e.y + o.x};
+        v[15 - s] = v2f{e.x + o.y, o.x - e.y};
+    }
+    v2f dc = v2f{0.f, 0.f};
+    if (is0) { float y0 = in[0].x * sc, yn = in[G::C].x * sc; dc = v2f{y0 + yn, y0 - yn}; }
+    lane0_unpermute<G>(v, is0, dc);
+    fft_inverse<G>(v, my, t, tw, sync);
+    if (live) {
+        v2f* ys = reinterpret_cast<v2f*>(frames + frame * N);
+#pragma unroll
+        for (int j = 0; j < 16; j++) ys[t + G::T * j] = v[j];
+    }
+}
+
+// =============================================================================================== host side
+static thread_local int g_last_hip = 0;
+#define HIPCHK(expr)                                         \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) { g_last_hip = (int)e_; return GOMEL_ERR_HIP; } \
+    } while (0)
+
+struct TableHeader {
+    uint32_t magic, version;
+    int32_t n, hop, k, hann_periodic;
+    double fmin, fmax;
+};
+static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
+
+struct gomel_handle {
+    gomel_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    int path_mode = 0;
+    std::vector<double> window;   // [N]
+    std::vector<BinRow> undo;     // [N/2]
+    std::vector<BinRow> dom;      // [K]
+    void* d_blob = nullptr;       // one device allocation for all tables
+    DevTables dt{};
+};
+
+static double hz_to_mel(double v) { return 1127.0 * std::log(1.0 + (v / 700.0)); }  // mel/impl.go:304-308
+static double mel_to_hz(double v) { return 700.0 * (std::exp(v / 1127.0) - 1.0); }  // mel/impl.go:298-302
+
+static int classify_row(double vallo, double valhi, bool undomel_rules, int limit, BinRow* r) {
+    double inlo, modlo = std::modf(vallo, &inlo);
+    double inhi = std::floor(valhi);
+    if (inlo < 0) { inlo = 0; modlo = 0; inhi = 0; }  // note: -0.0 < 0 is false, exactly as in Go
+    long lo = (long)inlo, hi = (long)inhi;
+    r->lo = (int32_t)lo; r->hi = (int32_t)hi; r->modlo = modlo; r->pad_ = 0; r->div = 1;
+    if (undomel_rules) {  // mel/impl.go:365-375
+        if (lo == hi) { r->mode = 0; if (lo < 0 || lo >= limit) return GOMEL_ERR_TABLE_RANGE; }
+        else if (lo + 1 == hi && hi < limit) { r->mode = 1; if (lo < 0) return GOMEL_ERR_TABLE_RANGE; }
+        else { r->mode = 2; r->div = inhi - inlo + 1; if (hi > lo && (lo < 0 || hi > limit)) return GOMEL_ERR_TABLE_RANGE; }
+    } else {  // domel, mel/impl.go:328-336
+        if (lo + 1 == hi) { r->mode = 1; if (lo < 0 || hi >= limit) return GOMEL_ERR_TABLE_RANGE; }
+        else { r->mode = 2; r->div = (double)(hi - lo + 1); if (hi > lo && (lo < 0 || hi > limit)) return GOMEL_ERR_TABLE_RANGE; }
+    }
+    return GOMEL_OK;
+}
+
+static int build_mel_tables(const gomel_config& c, std::vector<BinRow>& undo, std::vector<BinRow>& dom, int* dom_status) {
+    const int H = c.resolut / 2, K = c.num_mels;
+    const double fmin = c.mel_fmin, fmax = c.mel_fmax;
+    undo.resize(H);
+    const double filterbin = hz_to_mel(fmax) / (double)K;  // mel/impl.go:348
+    for (int i = 0; i < H; i++) {
+        double vallo = hz_to_mel(((double)i * (fmax + fmin) / (double)H) - fmin) / filterbin;
+        double valhi = hz_to_mel(((double)(i + 1) * (fmax + fmin) / (double)H) - fmin) / filterbin;
+        int rc = classify_row(vallo, valhi, true, K, &undo[i]);
+        if (rc) return rc;
+    }
+    dom.resize(K);
+    *dom_status = GOMEL_OK;
+    const double melbin = hz_to_mel(fmax) / (double)K;  // mel/impl.go:311
+    for (int i = 0; i < K; i++) {
+        double vallo = (double)H * (fmin + mel_to_hz(melbin * (double)i)) / (fmax + fmin);
+        double valhi = (double)H * (fmin + mel_to_hz(melbin * (double)(i + 1))) / (fmax + fmin);
+        int rc = classify_row(vallo, valhi, false, H, &dom[i]);
+        if (rc) { *dom_status = rc; dom[i].mode = 2; dom[i].lo = dom[i].hi = 0; dom[i].div = 1; }
+    }
+    return GOMEL_OK;
+}
+
+static int validate_config(const gomel_config* c) {
+    if (!c) return GOMEL_ERR_NULL;
+    if (c->num_mels <= 0 || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
+    if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
+    if (c->resolut != 1024 && c->resolut != 2048 && c->resolut != 4096) return GOMEL_ERR_UNSUPPORTED_N;
+    if (c->window % 2 != 0) return GOMEL_ERR_BAD_CONFIG;  // float2 (8-byte) frame loads need an even hop
+    return GOMEL_OK;
+}
+
+template <class V> static void fill_twiddles(int N, int R1, int R2, std::vector<V>& tw1, std::vector<V>& tw2, std::vector<V>& wn) {
+    typedef typename ScalarOf<V>::type S;
+    const int C = N / 2, C1 = C / R1;
+    tw1.resize(C); tw2.resize(R2 * 8); wn.resize(C);
+    for (int q = 0; q < R1; q++)
+        for (int t1 = 0; t1 < C1; t1++) {
+            double a = -2.0 * M_PI * (double)((int64_t)t1 * q % C) / (double)C;
+            tw1[q * C1 + t1] = V{(S)std::cos(a), (S)std::sin(a)};
+        }
+    for (int q = 0; q < R2; q++)
+        for (int t2 = 0; t2 < 8; t2++) {
+            double a = -2.0 * M_PI * (double)(t2 * q % C1) / (double)C1;
+            tw2[q * 8 + t2] = V{(S)std::cos(a), (S)std::sin(a)};
+        }
+    for (int k = 0; k < C; k++) {
+        double a = -2.0 * M_PI * (double)k / (double)N;
+        wn[k] = V{(S)std::cos(a), (S)std::sin(a)};
+    }
+}
+
+static int upload_tables(gomel_handle* h) {
+    const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
+    const int R1 = (N == 1024) ? 8 : 16, R2 = (N == 4096) ? 16 : 8;
+    std::vector<v2f> tw1, tw2, wn;
+    std::vector<v2d> tw1d, tw2d, wnd;
+    fill_twiddles<v2f>(N, R1, R2, tw1, tw2, wn);
+    fill_twiddles<v2d>(N, R1, R2, tw1d, tw2d, wnd);
+    std::vector<float> wf(N);
+    for (int i = 0; i < N; i++) wf[i] = (float)h->window[i];
+    // carve one allocation, every piece 256-byte aligned
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    size_t o_win = carve(N * 4), o_tw1 = carve(C * 8), o_tw2 = carve(R2 * 8 * 8), o_wn = carve(C * 8);
+    size_t o_tw1d = carve(C * 16), o_tw2d = carve(R2 * 8 * 16), o_wnd = carve(C * 16), o_wind = carve(N * 8);
+    size_t o_undo = carve(C * sizeof(BinRow)), o_dom = carve(K * sizeof(BinRow));
+    std::vector<char> host(off);
+    memcpy(&host[o_win], wf.data(), N * 4);
+    memcpy(&host[o_tw1], tw1.data(), C * 8); memcpy(&host[o_tw2], tw2.data(), R2 * 8 * 8); memcpy(&host[o_wn], wn.data(), C * 8);
+    memcpy(&host[o_tw1d], tw1d.data(), C * 16); memcpy(&host[o_tw2d], tw2d.data(), R2 * 8 * 16); memcpy(&host[o_wnd], wnd.data(), C * 16);
+    memcpy(&host[o_wind], h->window.data(), N * 8);
+    memcpy(&host[o_undo], h->undo.data(), C * sizeof(BinRow)); memcpy(&host[o_dom], h->dom.data(), K * sizeof(BinRow));
+    if (!h->d_blob) HIPCHK(hipMalloc(&h->d_blob, off));
+    HIPCHK(hipMemcpy(h->d_blob, host.data(), off, hipMemcpyHostToDevice));
+    char* d = (char*)h->d_blob;
+    h->dt.window = (const float*)(d + o_win);
+    h->dt.tw1 = (const v2f*)(d + o_tw1); h->dt.tw2 = (const v2f*)(d + o_tw2); h->dt.wn = (const v2f*)(d + o_wn);
+    h->dt.tw1d = (const v2d*)(d + o_tw1d); h->dt.tw2d = (const v2d*)(d + o_tw2d); h->dt.wnd = (const v2d*)(d + o_wnd);
+    h->dt.windowd = (const double*)(d + o_wind);
+    h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
+    return GOMEL_OK;
+}
+
+static int dom_status_of(const gomel_handle* h) {
+    for (const BinRow& r : h->dom) if (r.mode == 2 && r.lo == 0 && r.hi == 0 && r.div == 1 && &r != &h->dom[0]) return GOMEL_ERR_TABLE_RANGE;
+    return GOMEL_OK;
+}
+
+static int create_common(const gomel_config* cfg, const void* blob, size_t blob_bytes, gomel_handle** out) {
+    if (!cfg || !out) return GOMEL_ERR_NULL;
+    *out = nullptr;
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOMEL_ERR_NO_DEVICE;
+    gomel_handle* h = new (std::nothrow) gomel_handle();
+    if (!h) return GOMEL_ERR_HIP;
+    h->cfg = *cfg;
+    if (cfg->device >= 0) {
+        if (cfg->device >= ndev) { delete h; return GOMEL_ERR_NO_DEVICE; }
+        h->device = cfg->device;
+    } else if (hipGetDevice(&h->device) != hipSuccess) { delete h; return GOMEL_ERR_NO_DEVICE; }
+    const int N = cfg->resolut, C = N / 2, K = cfg->num_mels;
+    if (blob) {
+        const size_t need = sizeof(TableHeader) + (size_t)N * 8 + ((size_t)C + K) * sizeof(BinRow);
+        TableHeader th;
+        if (blob_bytes != need) { delete h; return GOMEL_ERR_BAD_TABLES; }
+        memcpy(&th, blob, sizeof th);
+        if (th.magic != kMagic || th.version != GOMEL_HIP_ABI_VERSION || th.n != N || th.hop != cfg->window || th.k != K ||
+            th.fmin != cfg->mel_fmin || th.fmax != cfg->mel_fmax) { delete h; return GOMEL_ERR_BAD_TABLES; }
+        const char* p = (const char*)blob + sizeof th;
+        h->window.resize(N); memcpy(h->window.data(), p, (size_t)N * 8); p += (size_t)N * 8;
+        h->undo.resize(C); memcpy(h->undo.data(), p, (size_t)C * sizeof(BinRow)); p += (size_t)C * sizeof(BinRow);
+        h->dom.resize(K); memcpy(h->dom.data(), p, (size_t)K * sizeof(BinRow));
+        h->cfg.hann_periodic = th.hann_periodic;
+    } else {
+        h->window.resize(N);
+        const double arg = 2.0 * M_PI / (double)(cfg->hann_periodic ? N : N - 1);  // gossp window.CreateHanning
+        for (int i = 0; i < N; i++) h->window[i] = 0.5 - 0.5 * std::cos(arg * (double)i);
+        int dom_rc = GOMEL_OK;
+        rc = build_mel_tables(*cfg, h->undo, h->dom, &dom_rc);
+        if (rc) { delete h; return rc; }
+    }
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h; return GOMEL_ERR_HIP;
+    }
+    rc = upload_tables(h);
+    if (rc) { hipStreamDestroy(h->stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
+    *out = h;
+    return GOMEL_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- batch
+struct gomel_batch {
+    gomel_handle* h = nullptr;
+    size_t n_utt = 0;
+    std::vector<UttDesc> utts;
+    std::vector<size_t> n_pairs;
+    int64_t total_frames = 0, total_len = 0, total_pairs = 0, max_len = 0;
+    bool any_x0 = false, uploaded = false;
+    int fast = 0;
+    // device
+    double* d_mel = nullptr;   // [total_pairs][2]
+    double* d_x0 = nullptr;    // [total_len] (only when some x0 is given)
+    double* d_out = nullptr;   // [total_len]
+    float* d_mag = nullptr;    // [total_frames][N/2]
+    float* d_nyq = nullptr;    // [total_frames]
+    float* d_x[2] = {nullptr, nullptr};  // ping-pong signal
+    float* d_yw = nullptr;     // generic path: [total_frames][N]
+    int64_t* d_frame_xoff = nullptr;
+    UttDesc* d_utts = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+static void batch_free(gomel_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->h->device);
+    void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& e : b->ev) if (e) hipEventDestroy(e);
+    delete b;
+}
+
+static bool fused_applicable(const gomel_config& c) {
+    (void)c;
+    return false;  // the fused sliding-window kernel is added in gl_fused (see below)
+}
+
+template <int N> static void launch_frames(gomel_batch* b, const float* x) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    const int64_t blocks = (b->total_frames + STREAMS - 1) / STREAMS;
+    hipLaunchKernelGGL(k_gl_frames<N>, dim3((unsigned)blocks), dim3(128), 0, b->h->stream, x, b->d_frame_xoff, b->d_mag, b->d_nyq, b->d_yw,
+                       b->total_frames, b->h->dt);
+}
+
+static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
+    gomel_handle* h = b->h;
+    const gomel_config& c = h->cfg;
+    const int N = c.resolut, H = N / 2, K = c.num_mels, I = c.griffin_lim_iterations;
+    hipStream_t s = h->stream;
+    if (!b->uploaded) return GOMEL_ERR_NULL;
+    if (tm) HIPCHK(hipEventRecord(b->ev[0], s));
+    const unsigned gx = (unsigned)std::min<int64_t>((b->max_len + 255) / 256, 4096);
+    if (I == 0) {
+        // "I = 0 returns the random init" (mel/mel.go:85 never runs): keep it in fp64
+        hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_out);
+        if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
+    } else {
+        hipLaunchKernelGGL(k_mel_to_mag, dim3((unsigned)b->total_frames), dim3(256), (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_mag,
+                           b->d_nyq, K, H, c.tune_add, c.tune_mul, 1.0 / (double)N);
+        hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
+        if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
+        int cur = 0;
+        for (int it = 0; it < I; it++) {
+            if (N == 4096) launch_frames<4096>(b, b->d_x[cur]);
+            else if (N == 2048) launch_frames<2048>(b, b->d_x[cur]);
+            else launch_frames<1024>(b, b->d_x[cur]);
+            hipLaunchKernelGGL(k_ola, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
+            cur ^= 1;
+        }
+        if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
+        const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_finalize, dim3(gf), dim3(256), 0, s, b->d_x[cur], b->d_out, b->total_len);
+    }
+    HIPCHK(hipGetLastError());
+    if (tm) {
+        HIPCHK(hipEventRecord(b->ev[3], s));
+        HIPCHK(hipEventSynchronize(b->ev[3]));
+        HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
+        HIPCHK(hipEventElapsedTime(&tm->iter_ms, b->ev[1], b->ev[2]));
+        tm->iter_launches = I;
+        tm->fast_path = b->fast;
+        tm->frames = b->total_frames;
+    }
+    return GOMEL_OK;
+}
+
+template <int N> static void launch_fft(gomel_handle* h, bool inverse, const float* in, float* out, int64_t n_frames) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    const int64_t blocks = (n_frames + STREAMS - 1) / STREAMS;
+    if (!inverse) hipLaunchKernelGGL(k_rfft<N>, dim3((unsigned)blocks), dim3(128), 0, h->stream, in, out, n_frames, h->dt);
+    else hipLaunchKernelGGL(k_irfft<N>, dim3((unsigned)blocks), dim3(128), 0, h->stream, in, out, n_frames, h->dt);
+}
+
+static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_frames, float* out) {
+    if (!h || !in || !out) return GOMEL_ERR_NULL;
+    if (n_frames == 0) return GOMEL_ERR_EMPTY;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    const int N = h->cfg.resolut;
+    const size_t in_b = n_frames * (inverse ? (size_t)(N + 2) : (size_t)N) * 4, out_b = n_frames * (inverse ? (size_t)N : (size_t)(N + 2)) * 4;
+    float *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_in, in_b));
+    if (hipMalloc(&d_out, out_b) != hipSuccess) { hipFree(d_in); return GOMEL_ERR_HIP; }
+    int rc = GOMEL_OK;
+    if (hipMemcpyAsync(d_in, in, in_b, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc) {
+        if (N == 4096) launch_fft<4096>(h, inverse, d_in, d_out, (int64_t)n_frames);
+        else if (N == 2048) launch_fft<2048>(h, inverse, d_in, d_out, (int64_t)n_frames);
+        else launch_fft<1024>(h, inverse, d_in, d_out, (int64_t)n_frames);
+        if (hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
+        }
+    }
+    hipFree(d_in); hipFree(d_out);
+    return rc;
+}
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int gomel_abi_version(void) { return GOMEL_HIP_ABI_VERSION; }
+int gomel_last_hip_error(void) { return g_last_hip; }
+
+int gomel_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* gomel_strerror(int s) {
+    switch (s) {
+        case GOMEL_OK: return "ok";
+        case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax, or odd Window)";
+        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut must be 1024, 2048 or 4096";
+        case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
+        case GOMEL_ERR_EMPTY: return "empty input";
+        case GOMEL_ERR_TABLE_RANGE: return "mel table indexes outside the band/bin range for this configuration";
+        case GOMEL_ERR_BUFFER_TOO_SMALL: return "output buffer too small";
+        case GOMEL_ERR_NULL: return "null pointer or call out of order";
+        case GOMEL_ERR_HIP: return "HIP runtime error (see gomel_last_hip_error)";
+        case GOMEL_ERR_NO_DEVICE: return "no usable HIP device";
+        case GOMEL_ERR_BAD_TABLES: return "table blob does not match the configuration";
+        case GOMEL_ERR_TOO_SHORT: return "padded input shorter than one frame";
+        default: return "unknown status";
+    }
+}
+
+int gomel_default_config(gomel_config* c) {
+    if (!c) return GOMEL_ERR_NULL;
+    c->num_mels = 160; c->window = 256; c->resolut = 2048; c->griffin_lim_iterations = 2;  // mel/mel.go:30-41
+    c->mel_fmin = 0; c->mel_fmax = 8000; c->tune_mul = 1; c->tune_add = 0;
+    c->device = -1; c->hann_periodic = 0;
+    return GOMEL_OK;
+}
+
+int gomel_create(const gomel_config* cfg, gomel_handle** out) { return create_common(cfg, nullptr, 0, out); }
+int gomel_create_from_tables(const gomel_config* cfg, const void* blob, size_t n, gomel_handle** out) {
+    if (!blob) return GOMEL_ERR_NULL;
+    return create_common(cfg, blob, n, out);
+}
+
+size_t gomel_tables_bytes(const gomel_handle* h) {
+    if (!h) return 0;
+    return sizeof(TableHeader) + (size_t)h->cfg.resolut * 8 + ((size_t)h->cfg.resolut / 2 + h->cfg.num_mels) * sizeof(BinRow);
+}
+
+int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap) {
+    if (!h || !blob) return GOMEL_ERR_NULL;
+    if (cap < gomel_tables_bytes(h)) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, h->cfg.resolut, h->cfg.window, h->cfg.num_mels, h->cfg.hann_periodic, h->cfg.mel_fmin, h->cfg.mel_fmax};
+    char* p = (char*)blob;
+    memcpy(p, &th, sizeof th); p += sizeof th;
+    memcpy(p, h->window.data(), h->window.size() * 8); p += h->window.size() * 8;
+    memcpy(p, h->undo.data(), h->undo.size() * sizeof(BinRow)); p += h->undo.size() * sizeof(BinRow);
+    memcpy(p, h->dom.data(), h->dom.size() * sizeof(BinRow));
+    return GOMEL_OK;
+}
+
+int gomel_set_window(gomel_handle* h, const double* w, size_t n) {
+    if (!h || !w) return GOMEL_ERR_NULL;
+    if (n != (size_t)h->cfg.resolut) return GOMEL_ERR_BAD_LENGTH;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->window.assign(w, w + n);
+    return upload_tables(h);
+}
+
+int gomel_get_window(const gomel_handle* h, double* w, size_t cap) {
+    if (!h || !w) return GOMEL_ERR_NULL;
+    if (cap < h->window.size()) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    memcpy(w, h->window.data(), h->window.size() * 8);
+    return GOMEL_OK;
+}
+
+int gomel_set_path(gomel_handle* h, int mode) {
+    if (!h) return GOMEL_ERR_NULL;
+    if (mode < 0 || mode > 2) return GOMEL_ERR_BAD_CONFIG;
+    if (mode == 2 && !fused_applicable(h->cfg)) return GOMEL_ERR_BAD_CONFIG;
+    h->path_mode = mode;
+    return GOMEL_OK;
+}
+
+int gomel_destroy(gomel_handle* h) {
+    if (!h) return GOMEL_OK;
+    hipSetDevice(h->device);
+    if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
+    if (h->d_blob) hipFree(h->d_blob);
+    delete h;
+    return GOMEL_OK;
+}
+
+int gomel_device_name(const gomel_handle* h, char* buf, size_t cap) {
+    if (!h || !buf || cap == 0) return GOMEL_ERR_NULL;
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, h->device));
+    snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return GOMEL_OK;
+}
+
+size_t gomel_out_len(const gomel_config* c, size_t n_pairs) {
+    if (!c || c->num_mels <= 0 || n_pairs == 0 || n_pairs % (size_t)c->num_mels) return 0;
+    return (size_t)c->resolut + (n_pairs / (size_t)c->num_mels - 1) * (size_t)c->window;  // mel/mel.go:80
+}
+
+size_t gomel_pad_len(size_t n, int32_t window) {  // mel/impl.go:429-455
+    if (window <= 0) return n;
+    size_t mint = 15 * (size_t)window, padlen = 0;
+    if (n >= mint) {
+        size_t rem = (n - mint) % (size_t)window;
+        if (rem != 0) padlen = (size_t)window - rem - 1;
+    } else {
+        padlen = mint - n - 1;
+    }
+    return n + padlen;
+}
+
+int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.go:457-479
+    return gomel_pad_len(orig, window) == padded ? 1 : 0;
+}
+
+int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+    if (!h || !n_pairs || !out) return GOMEL_ERR_NULL;
+    *out = nullptr;
+    if (n_utt == 0) return GOMEL_ERR_EMPTY;
+    const gomel_config& c = h->cfg;
+    const int N = c.resolut, K = c.num_mels, hop = c.window;
+    for (size_t u = 0; u < n_utt; u++) {
+        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
+        if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    gomel_batch* b = new (std::nothrow) gomel_batch();
+    if (!b) return GOMEL_ERR_HIP;
+    b->h = h; b->n_utt = n_utt;
+    b->utts.resize(n_utt); b->n_pairs.assign(n_pairs, n_pairs + n_utt);
+    for (size_t u = 0; u < n_utt; u++) {
+        UttDesc& d = b->utts[u];
+        d.frames = (int32_t)(n_pairs[u] / (size_t)K);
+        d.len = (int64_t)N + (int64_t)(d.frames - 1) * hop;
+        d.xoff = b->total_len; d.fbase = b->total_frames; d.has_x0 = 0; d.seed = u;
+        b->total_len += (d.len + 1) & ~(int64_t)1;  // keep every utterance 8-byte aligned for float2 access
+        b->total_frames += d.frames; b->total_pairs += (int64_t)n_pairs[u];
+        b->max_len = std::max(b->max_len, d.len);
+    }
+    b->fast = (h->path_mode != 1 && fused_applicable(c)) ? 1 : 0;
+    const int I = c.griffin_lim_iterations;
+    int rc = GOMEL_OK;
+    auto alloc = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
+    alloc((void**)&b->d_mel, (size_t)b->total_pairs * 16);
+    alloc((void**)&b->d_out, (size_t)b->total_len * 8);
+    alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
+    if (I > 0) {
+        alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);
+        alloc((void**)&b->d_nyq, (size_t)b->total_frames * 4);
+        alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
+        alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
+        alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+        if (!b->fast) alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4);
+    }
+    for (auto& e : b->ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc && I > 0) {
+        std::vector<int64_t> fx((size_t)b->total_frames);
+        for (size_t u = 0; u < n_utt; u++)
+            for (int f = 0; f < b->utts[u].frames; f++) fx[(size_t)b->utts[u].fbase + f] = b->utts[u].xoff + (int64_t)f * hop;
+        if (hipMemcpy(b->d_frame_xoff, fx.data(), fx.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+    }
+    if (rc) { batch_free(b); return rc; }
+    *out = b;
+    return GOMEL_OK;
+}
+
+int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
+    if (!b || !mel) return GOMEL_ERR_NULL;
+    gomel_handle* h = b->h;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    b->any_x0 = false;
+    for (size_t u = 0; u < b->n_utt; u++) {
+        if (!mel[u]) return GOMEL_ERR_NULL;
+        b->utts[u].has_x0 = (x0 && x0[u]) ? 1 : 0;
+        b->utts[u].seed = seeds ? seeds[u] : (uint64_t)u;
+        b->any_x0 |= b->utts[u].has_x0 != 0;
+    }
+    if (b->any_x0 && !b->d_x0) HIPCHK(hipMalloc((void**)&b->d_x0, (size_t)b->total_len * 8));
+    int64_t poff = 0;
+    for (size_t u = 0; u < b->n_utt; u++) {
+        HIPCHK(hipMemcpyAsync(b->d_mel + poff * 2, mel[u], b->n_pairs[u] * 16, hipMemcpyHostToDevice, h->stream));
+        poff += (int64_t)b->n_pairs[u];
+        if (b->utts[u].has_x0)
+            HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    b->uploaded = true;
+    return GOMEL_OK;
+}
+
+int gomel_batch_run(gomel_batch* b) {
+    if (!b) return GOMEL_ERR_NULL;
+    std::lock_guard<std::mutex> lk(b->h->mu);
+    HIPCHK(hipSetDevice(b->h->device));
+    return batch_run_impl(b, nullptr);
+}
+
+int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t) {
+    if (!b || !t) return GOMEL_ERR_NULL;
+    std::lock_guard<std::mutex> lk(b->h->mu);
+    HIPCHK(hipSetDevice(b->h->device));
+    return batch_run_impl(b, t);
+}
+
+int gomel_batch_sync(gomel_batch* b) {
+    if (!b) return GOMEL_ERR_NULL;
+    std::lock_guard<std::mutex> lk(b->h->mu);
+    HIPCHK(hipSetDevice(b->h->device));
+    HIPCHK(hipStreamSynchronize(b->h->stream));
+    return GOMEL_OK;
+}
+
+int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap) {
+    if (!b || !out) return GOMEL_ERR_NULL;
+    gomel_handle* h = b->h;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    for (size_t u = 0; u < b->n_utt; u++) {
+        if (!out[u]) return GOMEL_ERR_NULL;
+        if (out_cap && out_cap[u] < (size_t)b->utts[u].len) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    }
+    for (size_t u = 0; u < b->n_utt; u++)
+        HIPCHK(hipMemcpyAsync(out[u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GOMEL_OK;
+}
+
+int gomel_batch_destroy(gomel_batch* b) {
+    if (!b) return GOMEL_OK;
+    std::lock_guard<std::mutex> lk(b->h->mu);
+    hipSetDevice(b->h->device);
+    hipStreamSynchronize(b->h->stream);
+    batch_free(b);
+    return GOMEL_OK;
+}
+
+int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
+                         const uint64_t* seeds, double* const* out, const size_t* out_cap) {
+    if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
+    if (out_cap)
+        for (size_t u = 0; u < n_utt; u++) {
+            size_t L = gomel_out_len(&h->cfg, n_pairs[u]);
+            if (L && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+        }
+    gomel_batch* b = nullptr;
+    int rc = gomel_batch_create(h, n_utt, n_pairs, &b);
+    if (rc) return rc;
+    rc = gomel_batch_upload(b, mel, x0, seeds);
+    if (!rc) rc = gomel_batch_run(b);
+    if (!rc) rc = gomel_batch_download(b, out, out_cap);
+    gomel_batch_destroy(b);
+    return rc;
+}
+
+int gomel_from_mel(gomel_handle* h, const double* mel, size_t n_pairs, const double* x0, uint64_t seed, double* out, size_t out_cap,
+                   size_t* out_len) {
+    if (!h || !mel || !out) return GOMEL_ERR_NULL;
+    if (n_pairs == 0) return GOMEL_ERR_EMPTY;
+    if (n_pairs % (size_t)h->cfg.num_mels) return GOMEL_ERR_BAD_LENGTH;
+    const size_t L = gomel_out_len(&h->cfg, n_pairs);
+    if (out_cap < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    const double* mels[1] = {mel};
+    const double* x0s[1] = {x0};
+    double* outs[1] = {out};
+    int rc = gomel_from_mel_batch(h, 1, mels, &n_pairs, x0s, &seed, outs, &out_cap);
+    if (!rc && out_len) *out_len = L;
+    return rc;
+}
+
+int gomel_rfft_frames(gomel_handle* h, const float* frames, size_t n_frames, float* spectrum) { return fft_hook(h, false, frames, n_frames, spectrum); }
+int gomel_irfft_frames(gomel_handle* h, const float* spectrum, size_t n_frames, float* frames) { return fft_hook(h, true, spectrum, n_frames, frames); }
+
+int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, float* mag_out) {
+    if (!h || !mel || !mag_out) return GOMEL_ERR_NULL;
+    if (n_pairs == 0) return GOMEL_ERR_EMPTY;
+    const int K = h->cfg.num_mels, N = h->cfg.resolut, H = N / 2;
+    if (n_pairs % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
+    const size_t F = n_pairs / (size_t)K;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    double* d_mel = nullptr; float *d_mag = nullptr, *d_nyq = nullptr;
+    int rc = GOMEL_OK;
+    if (hipMalloc((void**)&d_mel, n_pairs * 16) != hipSuccess || hipMalloc((void**)&d_mag, F * H * 4) != hipSuccess ||
+        hipMalloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc && hipMemcpyAsync(d_mel, mel, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_mel_to_mag, dim3((unsigned)F), dim3(256), (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, H,
+                           h->cfg.tune_add, h->cfg.tune_mul, 1.0 / (double)N);
+        std::vector<float> mg(F * H), ny(F);
+        if (hipMemcpyAsync(mg.data(), d_mag, F * H * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipMemcpyAsync(ny.data(), d_nyq, F * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+        if (!rc)
+            for (size_t f = 0; f < F; f++) {
+                memcpy(mag_out + f * (H + 1), mg.data() + f * H, (size_t)H * 4);
+                mag_out[f * (H + 1) + H] = ny[f];
+            }
+    }
+    if (d_mel) hipFree(d_mel);
+    if (d_mag) hipFree(d_mag);
+    if (d_nyq) hipFree(d_nyq);
+    return rc;
+}
+
+size_t gomel_to_mel_pairs(const gomel_config* c, size_t n) {
+    if (!c || c->window <= 0 || c->resolut <= 0 || c->num_mels <= 0) return 0;
+    size_t p = gomel_pad_len(n, c->window);
+    if (p < (size_t)c->resolut) return 0;
+    long F = (long)((double)(p - (size_t)c->resolut) / (double)c->window) + 1;  // gossp NumFrames
+    return (size_t)F * (size_t)c->num_mels;
+}
+
+int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+    (void)h; (void)wave; (void)n; (void)out_pairs; (void)cap_pairs; (void)n_pairs;
+    return GOMEL_ERR_BAD_CONFIG;  // implemented in the ToMel step
+}
+
+}  // extern "C"

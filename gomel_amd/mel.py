@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's Go package `mel` (mel/mel.go) over the C ABI in include/gomel_hip.h.
+
+Same exported names, argument meaning and error behaviour as the reference for the hot path:
+`NewMel`, `Mel.ToMel`, `Mel.FromMel`, `Mel.ToWavPng`, plus `Mel.ToMelWav`, `Mel.Image`, `LoadWav`, `SaveWav`,
+`ErrFileNotLoaded`.  All numerics run in libgomel_hip.so on the GPU; this module only marshals buffers and
+keeps the reference's host-side side effects (in-place exp, in-place VolumeBoost, SampleRate fallback).
+There is no CPU fallback.
+"""
+import ctypes
+import random
+
+import numpy as np
+
+from . import _lib
+from ._lib import GomelConfig, GomelError, GomelTiming, c_double_p, c_size_p, c_u64_p, check
+
+
+class ErrFileNotLoaded(Exception):
+    """mel/mel.go:43 `var ErrFileNotLoaded = errors.New("wavNotLoaded")`."""
+
+    def __init__(self):
+        super().__init__("wavNotLoaded")
+
+
+def _as_pairs(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError("expected an [n, 2] float64 array (Go [][2]float64)")
+    return a
+
+
+class Engine:
+    """One gomel_handle: configuration + device tables + stream (replaces stft.New and undomel's index math)."""
+
+    def __init__(self, cfg, tables=None):
+        self._h = ctypes.c_void_p()
+        self.cfg = cfg
+        L = _lib.lib()
+        if tables is None:
+            check(L.gomel_create(ctypes.byref(cfg), ctypes.byref(self._h)), "gomel_create")
+        else:
+            buf = (ctypes.c_char * len(tables)).from_buffer_copy(tables)
+            check(L.gomel_create_from_tables(ctypes.byref(cfg), buf, len(tables), ctypes.byref(self._h)), "gomel_create_from_tables")
+
+    def close(self):
+        if self._h:
+            _lib.lib().gomel_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- tables (the "mel basis" that rank 0 broadcasts) ---------------------------------------------
+    def export_tables(self):
+        L = _lib.lib()
+        n = L.gomel_tables_bytes(self._h)
+        buf = ctypes.create_string_buffer(n)
+        check(L.gomel_tables_export(self._h, buf, n), "gomel_tables_export")
+        return bytes(buf.raw)
+
+    def set_window(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        check(_lib.lib().gomel_set_window(self._h, w.ctypes.data_as(c_double_p), w.size), "gomel_set_window")
+
+    def get_window(self):
+        w = np.zeros(self.cfg.resolut)
+        check(_lib.lib().gomel_get_window(self._h, w.ctypes.data_as(c_double_p), w.size), "gomel_get_window")
+        return w
+
+    def set_path(self, mode):
+        check(_lib.lib().gomel_set_path(self._h, int(mode)), "gomel_set_path")
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        check(_lib.lib().gomel_device_name(self._h, buf, 256), "gomel_device_name")
+        return buf.value.decode()
+
+    def out_len(self, n_pairs):
+        return _lib.lib().gomel_out_len(ctypes.byref(self.cfg), n_pairs)
+
+    # -- FromMel -------------------------------------------------------------------------------------
+    def from_mel(self, mel_pairs, x0=None, seed=0):
+        m = _as_pairs(mel_pairs)
+        L = _lib.lib()
+        n = self.out_len(len(m)) if len(m) else 0
+        out = np.empty(max(n, 1), dtype=np.float64)
+        x0p = None
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            if x0.shape != (n,):
+                raise ValueError("x0 must have length %d" % n)
+            x0p = x0.ctypes.data_as(c_double_p)
+        got = ctypes.c_size_t(0)
+        check(L.gomel_from_mel(self._h, m.ctypes.data_as(c_double_p), len(m), x0p, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                               out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_from_mel")
+        return out[:got.value]
+
+    def from_mel_batch(self, mels, x0s=None, seeds=None):
+        b = Batch(self, [len(m) for m in mels])
+        try:
+            b.upload(mels, x0s, seeds)
+            b.run()
+            return b.download()
+        finally:
+            b.close()
+
+    def target_magnitudes(self, mel_pairs):
+        m = _as_pairs(mel_pairs)
+        H = self.cfg.resolut // 2
+        F = len(m) // self.cfg.num_mels
+        out = np.empty((max(F, 1), H + 1), dtype=np.float32)
+        check(_lib.lib().gomel_target_magnitudes(self._h, m.ctypes.data_as(c_double_p), len(m), out.ctypes.data_as(_lib.c_float_p)),
+              "gomel_target_magnitudes")
+        return out
+
+    # -- ToMel ---------------------------------------------------------------------------------------
+    def to_mel(self, wave):
+        w = np.ascontiguousarray(wave, dtype=np.float64)
+        L = _lib.lib()
+        cap = L.gomel_to_mel_pairs(ctypes.byref(self.cfg), w.size)
+        out = np.empty((max(cap, 1), 2), dtype=np.float64)
+        got = ctypes.c_size_t(0)
+        check(L.gomel_to_mel(self._h, w.ctypes.data_as(c_double_p), w.size, out.ctypes.data_as(c_double_p), cap, ctypes.byref(got)), "gomel_to_mel")
+        return out[:got.value]
+
+    # -- FFT test hooks ------------------------------------------------------------------------------
+    def rfft_frames(self, frames):
+        f = np.ascontiguousarray(frames, dtype=np.float32)
+        N = self.cfg.resolut
+        assert f.ndim == 2 and f.shape[1] == N
+        out = np.empty((f.shape[0], N // 2 + 1, 2), dtype=np.float32)
+        check(_lib.lib().gomel_rfft_frames(self._h, f.ctypes.data_as(_lib.c_float_p), f.shape[0], out.ctypes.data_as(_lib.c_float_p)), "gomel_rfft_frames")
+        return out[..., 0] + 1j * out[..., 1]
+
+    def irfft_frames(self, spec):
+        N = self.cfg.resolut
+        s = np.asarray(spec)
+        assert s.ndim == 2 and s.shape[1] == N // 2 + 1
+        buf = np.ascontiguousarray(np.stack([s.real, s.imag], axis=2), dtype=np.float32)
+        out = np.empty((s.shape[0], N), dtype=np.float32)
+        check(_lib.lib().gomel_irfft_frames(self._h, buf.ctypes.data_as(_lib.c_float_p), s.shape[0], out.ctypes.data_as(_lib.c_float_p)), "gomel_irfft_frames")
+        return out
+
+
+class Batch:
+    """Device-resident batch of independent utterances (create -> upload -> run -> download)."""
+
+    def __init__(self, engine, n_pairs):
+        self.engine = engine
+        self.n_pairs = [int(n) for n in n_pairs]
+        self._b = ctypes.c_void_p()
+        arr = (ctypes.c_size_t * len(self.n_pairs))(*self.n_pairs)
+        check(_lib.lib().gomel_batch_create(engine._h, len(self.n_pairs), arr, ctypes.byref(self._b)), "gomel_batch_create")
+        self.lens = [engine.out_len(n) for n in self.n_pairs]
+        self._keep = None
+
+    def upload(self, mels, x0s=None, seeds=None):
+        n = len(self.n_pairs)
+        ms = [_as_pairs(m) for m in mels]
+        if len(ms) != n or any(len(m) != k for m, k in zip(ms, self.n_pairs)):
+            raise ValueError("mel shapes do not match the batch plan")
+        mp = (c_double_p * n)(*[m.ctypes.data_as(c_double_p) for m in ms])
+        xp = None
+        xs = None
+        if x0s is not None:
+            xs = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in x0s]
+            for x, L in zip(xs, self.lens):
+                if x is not None and x.shape != (L,):
+                    raise ValueError("x0 length mismatch")
+            xp = (c_double_p * n)(*[None if x is None else x.ctypes.data_as(c_double_p) for x in xs])
+        sp = None
+        if seeds is not None:
+            sp = (ctypes.c_uint64 * n)(*[int(s) & (2 ** 64 - 1) for s in seeds])
+        self._keep = (ms, xs)
+        check(_lib.lib().gomel_batch_upload(self._b, mp, xp, sp), "gomel_batch_upload")
+        self._keep = None
+
+    def run(self):
+        check(_lib.lib().gomel_batch_run(self._b), "gomel_batch_run")
+
+    def run_timed(self):
+        t = GomelTiming()
+        check(_lib.lib().gomel_batch_run_timed(self._b, ctypes.byref(t)), "gomel_batch_run_timed")
+        return {"total_ms": t.total_ms, "iter_ms": t.iter_ms, "iter_launches": t.iter_launches, "fast_path": t.fast_path,
+                "frames": t.frames}
+
+    def sync(self):
+        check(_lib.lib().gomel_batch_sync(self._b), "gomel_batch_sync")
+
+    def download(self):
+        n = len(self.n_pairs)
+        outs = [np.empty(L, dtype=np.float64) for L in self.lens]
+        op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
+        caps = (ctypes.c_size_t * n)(*self.lens)
+        check(_lib.lib().gomel_batch_download(self._b, op, caps), "gomel_batch_download")
+        return outs
+
+    def close(self):
+        if self._b:
+            _lib.lib().gomel_batch_destroy(self._b)
+            self._b = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mel:
+    """`type Mel` (mel/mel.go:10-27).  Fields are plain attributes and may be changed between calls, as in Go."""
+
+    def __init__(self):
+        # NewMel defaults, mel/mel.go:30-41
+        self.NumMels = 160
+        self.MelFmin = 0.0
+        self.MelFmax = 8000.0
+        self.TuneMul = 1.0
+        self.TuneAdd = 0.0
+        self.Window = 256
+        self.Resolut = 2048
+        self.YReverse = False
+        self.GriffinLimIterations = 2
+        self.VolumeBoost = 0.0
+        self.SampleRate = 0
+        # not in the reference: which GPU, and which Hann definition (see DESIGN.md "window")
+        self.Device = -1
+        self.HannPeriodic = False
+        self._engines = {}
+
+    def _config(self):
+        c = GomelConfig()
+        c.num_mels, c.window, c.resolut = int(self.NumMels), int(self.Window), int(self.Resolut)
+        c.griffin_lim_iterations = int(self.GriffinLimIterations)
+        c.mel_fmin, c.mel_fmax = float(self.MelFmin), float(self.MelFmax)
+        c.tune_mul, c.tune_add = float(self.TuneMul), float(self.TuneAdd)
+        c.device, c.hann_periodic = int(self.Device), int(bool(self.HannPeriodic))
+        return c
+
+    def engine(self):
+        c = self._config()
+        key = (c.num_mels, c.window, c.resolut, c.griffin_lim_iterations, c.mel_fmin, c.mel_fmax, c.tune_mul, c.tune_add,
+               c.device, c.hann_periodic)
+        e = self._engines.get(key)
+        if e is None:
+            e = Engine(c)
+            self._engines = {key: e}  # one live handle per Mel object
+        return e
+
+    # mel/mel.go:46-74
+    def ToMel(self, buf):
+        return self.engine().to_mel(buf)
+
+    # mel/mel.go:142-152.  `x0`/`seed` stand in for Go's global math/rand source (mel/mel.go:81-83).
+    def FromMel(self, ospectrum, x0=None, seed=None):
+        if not (isinstance(ospectrum, np.ndarray) and ospectrum.dtype == np.float64 and ospectrum.flags.c_contiguous):
+            raise TypeError("FromMel wants a C-contiguous float64 [n,2] array: it is exp'd in place like the Go slice")
+        if seed is None:
+            seed = random.getrandbits(64)
+        wave = self.engine().from_mel(ospectrum, x0=x0, seed=seed)
+        np.exp(ospectrum, out=ospectrum)  # spectral_denormalize side effect on the caller's slice (mel/mel.go:143)
+        return wave
+
+    def FromMelBatch(self, spectra, x0s=None, seeds=None):
+        outs = self.engine().from_mel_batch(spectra, x0s, seeds)
+        for s in spectra:
+            np.exp(s, out=s)
+        return outs
+
+    # mel/mel.go:171-173
+    def Image(self, buf):
+        from . import codec
+        return codec.dumpbuffer(buf, self.NumMels)
+
+    # mel/mel.go:194-209
+    def ToMelWav(self, inputFile, outputFile):
+        from . import codec
+        buf, sr = codec.loadwav(inputFile)
+        if len(buf) == 0:
+            raise ErrFileNotLoaded()
+        osp = self.ToMel(buf)
+        codec.dumpimage(outputFile, osp, self.NumMels, self.YReverse, float(len(buf) * self.NumMels) / float(len(osp)), float(sr))
+
+    def ToMelFlac(self, inputFile, outputFile):
+        raise NotImplementedError("FLAC decoding (mewkiz/flac) is outside the accelerated path; decode to WAV first")
+
+    # mel/mel.go:211-238
+    def ToWavPng(self, inputFile, outputFile, x0=None, seed=None):
+        from . import codec
+        buf, samples, samplerate = codec.loadpng(inputFile, self.YReverse)
+        if len(buf) == 0:
+            raise ErrFileNotLoaded()
+        buf += self.VolumeBoost  # mel.go:218-221, log domain, in place
+        owave = self.FromMel(buf, x0=x0, seed=seed)
+        if int(samples) > 0 and _lib.lib().gomel_is_padded(int(samples), len(owave), int(self.Window)) and len(owave) > int(samples):
+            owave = owave[:int(samples)]
+        if samplerate != 0 and self.SampleRate == 0:
+            self.SampleRate = int(samplerate)
+        codec.dumpwav(outputFile, owave, self.SampleRate)  # the reference drops this error (mel.go:235)
+        return None
+
+
+def NewMel():
+    """mel/mel.go:30-41."""
+    return Mel()
+
+
+def LoadWav(inputFile):
+    """mel/mel.go:161-164."""
+    from . import codec
+    return codec.loadwav(inputFile)[0]
+
+
+def LoadFlac(inputFile):
+    raise NotImplementedError("FLAC decoding is outside the accelerated path")
+
+
+def SaveWav(outputFile, vec, sr):
+    """mel/mel.go:167-169."""
+    from . import codec
+    return codec.dumpwav(outputFile, vec, sr)

@@ -1,0 +1,146 @@
+/* gomel_hip.h -- C ABI of libgomel_hip.so: the MI355X (gfx950) Griffin-Lim mel-inversion engine that sits
+ * behind gomel's Go package API `github.com/neurlang/gomel/mel`.
+ *
+ * The reference has no FFI today (pure Go).  These entry points are what a cgo shim for the hot path binds
+ * (bindings/go/mel/mel_hip.go).  Each one names the reference interface it replaces
+ * (file:line relative to the reference repository).  Plain pointers and sizes only; every function returns a
+ * gomel_status (0 = ok) and never throws or aborts across the boundary.  Conditions on which the Go code
+ * panics (empty input, len % NumMels != 0, mel table running past the slice) come back as status codes.
+ *
+ * Layouts: a Go `[][2]float64` is one contiguous `double[2*n]`, frame-major: element (f*NumMels + k)*2 + c is
+ * channel c of mel band k of frame f (producer domel mel/impl.go:313-341, consumer undomel mel/impl.go:350).
+ * Waveforms are `double[L]`, L = Resolut + (F-1)*Window (mel/mel.go:80).
+ *
+ * Threading: a handle may be used from concurrent host threads; calls on one handle are serialised by an
+ * internal mutex and every entry sets the HIP device of the handle on the calling thread.
+ */
+#ifndef GOMEL_HIP_H
+#define GOMEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOMEL_HIP_ABI_VERSION 1
+
+typedef enum gomel_status {
+    GOMEL_OK = 0,
+    GOMEL_ERR_BAD_CONFIG = 1,     /* NumMels/Window/Resolut <= 0, TuneMul == 0, fmax+fmin <= 0 ...                 */
+    GOMEL_ERR_UNSUPPORTED_N = 2,  /* Resolut not in {1024, 2048, 4096} (reference: any N, Bluestein if not 2^k)  */
+    GOMEL_ERR_BAD_LENGTH = 3,     /* n_pairs % NumMels != 0 (reference: index panic, mel/impl.go:366)             */
+    GOMEL_ERR_EMPTY = 4,          /* zero frames (reference: index panic at mel/mel.go:78)                        */
+    GOMEL_ERR_TABLE_RANGE = 5,    /* undomel/domel table indexes past the band/bin slice (reference: panic)       */
+    GOMEL_ERR_BUFFER_TOO_SMALL = 6,
+    GOMEL_ERR_NULL = 7,
+    GOMEL_ERR_HIP = 8,            /* a HIP runtime call failed; gomel_last_hip_error() has the hipError_t         */
+    GOMEL_ERR_NO_DEVICE = 9,
+    GOMEL_ERR_BAD_TABLES = 10,    /* injected table blob does not match the configuration                         */
+    GOMEL_ERR_TOO_SHORT = 11      /* ToMel: padded input shorter than one frame                                   */
+} gomel_status;
+
+/* Mirrors `type Mel` (mel/mel.go:10-27).  YReverse, VolumeBoost and SampleRate only matter to the PNG/WAV
+ * codec, which stays on the host side of the boundary (ToWavPng mel/mel.go:211-238). */
+typedef struct gomel_config {
+    int32_t num_mels;               /* NumMels                                   default 160  */
+    int32_t window;                 /* Window  = hop (gossp frameShift)          default 256  */
+    int32_t resolut;                /* Resolut = frame / FFT length N            default 2048 */
+    int32_t griffin_lim_iterations; /* GriffinLimIterations                      default 2    */
+    double mel_fmin;                /* MelFmin  default 0    */
+    double mel_fmax;                /* MelFmax  default 8000 */
+    double tune_mul;                /* TuneMul  default 1    */
+    double tune_add;                /* TuneAdd  default 0    */
+    int32_t device;                 /* HIP device ordinal; -1 = the calling thread's current device */
+    int32_t hann_periodic;          /* 0 = symmetric Hann 0.5-0.5cos(2 pi n/(N-1)) (gossp window.CreateHanning, assumed);
+                                       1 = periodic (2 pi n/N).  gomel_set_window() injects any other table. */
+} gomel_config;
+
+typedef struct gomel_handle gomel_handle; /* configuration + device tables + stream       */
+typedef struct gomel_batch gomel_batch;   /* device-resident batch of utterances           */
+
+/* Per-run timing, measured with HIP events on the handle's stream. */
+typedef struct gomel_timing {
+    float total_ms;        /* mel->magnitude + x0 init + all iterations + finalize                        */
+    float iter_ms;         /* the Griffin-Lim iteration launches only (sum over iterations)               */
+    int32_t iter_launches; /* number of dominant-kernel launches inside iter_ms                           */
+    int32_t fast_path;     /* 1 = fused sliding-window kernel, 0 = generic frames + overlap-add kernels   */
+    int64_t frames;        /* frames processed                                                            */
+} gomel_timing;
+
+/* NewMel() defaults, mel/mel.go:30-41 (device = -1, symmetric Hann). */
+int gomel_default_config(gomel_config* cfg);
+
+/* Replaces stft.New(m.Window, m.Resolut) (mel/mel.go:50,145) and the per-call index math of undomel/domel
+ * (mel/impl.go:311-322,348-359): builds Hann, FFT twiddles and the mel<->linear tables once, uploads them. */
+int gomel_create(const gomel_config* cfg, gomel_handle** out);
+
+/* Same, from a table blob exported by another handle (the multi-GPU path: rank 0 builds, the blob is broadcast
+ * over RCCL/xGMI, every rank creates from it).  Fails with GOMEL_ERR_BAD_TABLES if it does not match cfg. */
+int gomel_create_from_tables(const gomel_config* cfg, const void* blob, size_t blob_bytes, gomel_handle** out);
+size_t gomel_tables_bytes(const gomel_handle* h);
+int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap);
+
+/* Inject the analysis/synthesis window (s.Window, mel/mel.go:92,120): n must equal Resolut. */
+int gomel_set_window(gomel_handle* h, const double* window, size_t n);
+int gomel_get_window(const gomel_handle* h, double* window, size_t cap);
+
+int gomel_destroy(gomel_handle* h);
+
+/* len(reconstructedSignal), mel/mel.go:80.  0 on bad arguments. */
+size_t gomel_out_len(const gomel_config* cfg, size_t n_pairs);
+
+/* (*Mel).FromMel, mel/mel.go:142-152 = spectral_denormalize + undomel + undospectrum + ISTFT (Griffin-Lim).
+ *   mel_pairs : [n_pairs][2] log-domain mel, NOT modified (the Go shim applies the reference's in-place exp side
+ *               effect, mel/mel.go:143, to the caller's slice itself).
+ *   x0        : initial signal, L doubles, replacing rand.Float64() (mel/mel.go:81-83); NULL = generate
+ *               x0[i] = (splitmix64(seed + (i+1)*0x9E3779B97F4A7C15) >> 11) * 2^-53.
+ *   out       : L doubles; *out_len receives L. */
+int gomel_from_mel(gomel_handle* h, const double* mel_pairs, size_t n_pairs, const double* x0, uint64_t seed,
+                   double* out, size_t out_cap, size_t* out_len);
+
+/* Many independent FromMel calls in one go (utterances are independent: mel/mel.go:142-152 keeps no state).
+ * x0 may be NULL, and so may any x0[u]; seeds may be NULL (then seed = u). */
+int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel_pairs, const size_t* n_pairs,
+                         const double* const* x0, const uint64_t* seeds, double* const* out, const size_t* out_cap);
+
+/* The same work split so that inputs can be resident in HBM before the clock starts (bench / pipelines):
+ * create (plan + allocate) -> upload (H2D of log-mel and x0) -> run (all device work, asynchronous on the
+ * handle's stream) -> download (D2H of the waveforms, synchronises). */
+int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out);
+int gomel_batch_upload(gomel_batch* b, const double* const* mel_pairs, const double* const* x0, const uint64_t* seeds);
+int gomel_batch_run(gomel_batch* b);
+int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t); /* synchronises */
+int gomel_batch_sync(gomel_batch* b);
+int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap);
+int gomel_batch_destroy(gomel_batch* b);
+/* 0 = let the library choose; 1 = force the generic kernels; 2 = require the fused kernel (error if not applicable) */
+int gomel_set_path(gomel_handle* h, int mode);
+
+/* (*Mel).ToMel, mel/mel.go:46-74 = pad + gossp STFT + |S[j]|,|S[N-1-j]| + domel + ln(max(v,1e-5)). */
+size_t gomel_to_mel_pairs(const gomel_config* cfg, size_t n_samples);
+int gomel_to_mel(gomel_handle* h, const double* wave, size_t n_samples, double* out_pairs, size_t cap_pairs,
+                 size_t* n_pairs);
+
+/* pad / isPadded, mel/impl.go:429-479 (ToWavPng's trim decision, mel/mel.go:228). */
+size_t gomel_pad_len(size_t n, int32_t window);
+int gomel_is_padded(size_t original_len, size_t padded_len, int32_t window);
+
+/* Test hooks for the FFT core (what fft.FFTReal / fft.IFFT do per frame, mel/mel.go:95,116):
+ * frames [n_frames][N] float -> spectrum [n_frames][N/2+1][2] float (unnormalised forward), and back (1/N). */
+int gomel_rfft_frames(gomel_handle* h, const float* frames, size_t n_frames, float* spectrum);
+int gomel_irfft_frames(gomel_handle* h, const float* spectrum, size_t n_frames, float* frames);
+/* The magnitudes the iteration clamps to: [F][N/2+1] float, already divided by N (the iFFT scale is folded in). */
+int gomel_target_magnitudes(gomel_handle* h, const double* mel_pairs, size_t n_pairs, float* mag_out);
+
+const char* gomel_strerror(int status);
+int gomel_last_hip_error(void);
+int gomel_abi_version(void);
+int gomel_device_count(void);
+int gomel_device_name(const gomel_handle* h, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOMEL_HIP_H */

@@ -1,0 +1,140 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Tolerances: the Griffin-Lim waveform must match the fp64 oracle within 1e-4 RMS (BASELINE.json north_star); the FFT
+hooks within 2e-6 relative to the frame's largest bin (fp32 arithmetic)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-4  # north_star: "matching the reference FromMel output sample-for-sample within 1e-4 RMS"
+
+GEOMS = {
+    "T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096),   # cmd/towav/main.go:30-36
+    "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),      # BASELINE config 4
+    "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048),     # NewMel defaults mel/mel.go:30-41
+}
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a))))
+
+
+def make_mel(geom, iters, **kw):
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    for k, v in dict(GEOMS[geom], GriffinLimIterations=iters, **kw).items():
+        setattr(m, k, v)
+    return m
+
+
+def ocfg(oracle, geom, iters, **kw):
+    return oracle.MelConfig(**dict(GEOMS[geom], GriffinLimIterations=iters, **kw))
+
+
+@pytest.mark.parametrize("geom", ["T", "S", "D"])
+def test_rfft_irfft_hooks(geom):
+    m = make_mel(geom, 1)
+    e = m.engine()
+    N = m.Resolut
+    rng = np.random.default_rng(1)
+    frames = rng.standard_normal((7, N)).astype(np.float32)
+    frames[3] = 0.0
+    frames[3, 5] = 1.0          # a shifted impulse: flat magnitude, linear phase
+    frames[4] = 1.0             # DC only
+    frames[5] = np.cos(np.pi * np.arange(N))  # Nyquist only
+    got = e.rfft_frames(frames)
+    ref = np.fft.rfft(frames.astype(np.float64), axis=1)
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert np.max(np.abs(got - ref) / scale) < 2e-6
+    back = e.irfft_frames(ref)
+    assert np.max(np.abs(back - frames)) < 5e-6 * max(1.0, float(np.abs(frames).max()))
+
+
+@pytest.mark.parametrize("geom", ["T", "S", "D"])
+def test_target_magnitudes(oracle, geom):
+    m = make_mel(geom, 1, TuneMul=1.25, TuneAdd=0.01)
+    cfg = ocfg(oracle, geom, 1, TuneMul=1.25, TuneAdd=0.01)
+    mel = oracle.random_logmel(5, cfg.NumMels, seed=11)
+    want = oracle.target_magnitudes(cfg, np.exp(mel)) / cfg.Resolut
+    got = m.engine().target_magnitudes(mel)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want) / (np.abs(want) + 1e-30)) < 2e-7
+
+
+@pytest.mark.parametrize("geom,frames", [("T", 4), ("T", 9), ("S", 8), ("S", 3), ("D", 6), ("T", 1)])
+@pytest.mark.parametrize("iters", [0, 1, 2, 60])
+def test_from_mel_matches_oracle(oracle, geom, frames, iters):
+    m = make_mel(geom, iters)
+    cfg = ocfg(oracle, geom, iters)
+    mel = oracle.random_logmel(frames, cfg.NumMels, seed=100 + frames)
+    L = oracle.out_len(cfg, len(mel))
+    x0 = oracle.x0_splitmix(7, L)
+    want = oracle.from_mel(cfg, mel.copy(), x0)
+    inp = mel.copy()
+    got = m.FromMel(inp, x0=x0)
+    assert got.shape == (L,)
+    assert np.all(np.isfinite(got))
+    if iters == 0:
+        assert np.array_equal(got, x0)          # mel.go:85 never runs: the init comes back untouched
+    else:
+        assert rms(got - want) < RMS_TOL, (rms(got - want), rms(want))
+    assert np.allclose(inp, np.exp(mel), rtol=1e-15)  # FromMel leaves the caller's slice exp'd (mel.go:143)
+
+
+def test_seed_generator_matches_documented_splitmix(oracle):
+    m = make_mel("S", 0)
+    mel = oracle.random_logmel(4, 80, seed=1)
+    got = m.FromMel(mel.copy(), seed=12345)
+    assert np.array_equal(got, oracle.x0_splitmix(12345, len(got)))
+    m2 = make_mel("S", 2)
+    a = m2.FromMel(mel.copy(), seed=99)
+    b = m2.FromMel(mel.copy(), x0=oracle.x0_splitmix(99, len(a)))
+    assert rms(a - b) < 1e-6
+
+
+def test_ragged_batch_equals_single_calls(oracle):
+    m = make_mel("S", 3)
+    cfg = ocfg(oracle, "S", 3)
+    fr = [3, 17, 1, 8, 40]
+    mels = [oracle.random_logmel(f, 80, seed=i) for i, f in enumerate(fr)]
+    x0s = [oracle.x0_splitmix(50 + i, oracle.out_len(cfg, len(mm))) for i, mm in enumerate(mels)]
+    x0s[2] = None
+    outs = m.FromMelBatch([mm.copy() for mm in mels], x0s, seeds=[0, 0, 77, 0, 0])
+    for i, (mm, o) in enumerate(zip(mels, outs)):
+        x0 = x0s[i] if x0s[i] is not None else oracle.x0_splitmix(77, oracle.out_len(cfg, len(mm)))
+        want = oracle.from_mel(cfg, mm.copy(), x0)
+        assert rms(o - want) < RMS_TOL
+
+
+def test_injected_window_and_periodic_hann(oracle):
+    m = make_mel("S", 2)
+    m.HannPeriodic = True
+    cfg = ocfg(oracle, "S", 2)
+    mel = oracle.random_logmel(6, 80, seed=5)
+    x0 = oracle.x0_splitmix(3, oracle.out_len(cfg, len(mel)))
+    want = oracle.from_mel(cfg, mel.copy(), x0, window=oracle.hann(1024, symmetric=False))
+    got = m.FromMel(mel.copy(), x0=x0)
+    assert rms(got - want) < RMS_TOL
+    e = make_mel("S", 2).engine()
+    w = np.sqrt(oracle.hann(1024))
+    e.set_window(w)
+    want = oracle.from_mel(cfg, mel.copy(), x0, window=w)
+    assert rms(e.from_mel(mel, x0=x0) - want) < RMS_TOL
+
+
+def test_error_statuses():
+    import gomel_amd
+    m = make_mel("T", 2)
+    with pytest.raises(gomel_amd.GomelError) as ei:   # 183*80 pairs with K=192: the reference panics
+        m.FromMel(np.zeros((183 * 80, 2)))
+    assert ei.value.status == 3
+    with pytest.raises(gomel_amd.GomelError) as ei:
+        m.FromMel(np.zeros((0, 2)))
+    assert ei.value.status == 4
+    m.Resolut = 3000
+    with pytest.raises(gomel_amd.GomelError) as ei:
+        m.FromMel(np.zeros((192, 2)))
+    assert ei.value.status == 2

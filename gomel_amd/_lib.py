@@ -21,7 +21,7 @@ class GomelConfig(ctypes.Structure):
 
 
 class GomelTiming(ctypes.Structure):
-    _fields_ = [("total_ms", ctypes.c_float), ("iter_ms", ctypes.c_float), ("iter_launches", ctypes.c_int32),
+    _fields_ = [("total_ms", ctypes.c_float), ("iter_ms", ctypes.c_float), ("dom_ms", ctypes.c_float), ("iter_launches", ctypes.c_int32),
                 ("fast_path", ctypes.c_int32), ("frames", ctypes.c_int64)]
 
 

@@ -429,6 +429,7 @@ struct gomel_batch {
     int64_t* d_frame_xoff = nullptr;
     UttDesc* d_utts = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> dom_ev;  // 2 per iteration, created on the first timed run
 };
 
 static void batch_free(gomel_batch* b) {
@@ -437,6 +438,7 @@ static void batch_free(gomel_batch* b) {
     void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
+    for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
     delete b;
 }
 
@@ -459,7 +461,10 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     const int N = c.resolut, H = N / 2, K = c.num_mels, I = c.griffin_lim_iterations;
     hipStream_t s = h->stream;
     if (!b->uploaded) return GOMEL_ERR_NULL;
-    if (tm) HIPCHK(hipEventRecord(b->ev[0], s));
+    if (tm) {
+        while ((int)b->dom_ev.size() < 2 * I) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->dom_ev.push_back(e); }
+        HIPCHK(hipEventRecord(b->ev[0], s));
+    }
     const unsigned gx = (unsigned)std::min<int64_t>((b->max_len + 255) / 256, 4096);
     if (I == 0) {
         // "I = 0 returns the random init" (mel/mel.go:85 never runs): keep it in fp64
@@ -472,9 +477,11 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
         for (int it = 0; it < I; it++) {
+            if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
             if (N == 4096) launch_frames<4096>(b, b->d_x[cur]);
             else if (N == 2048) launch_frames<2048>(b, b->d_x[cur]);
             else launch_frames<1024>(b, b->d_x[cur]);
+            if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
             hipLaunchKernelGGL(k_ola, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
             cur ^= 1;
         }
@@ -488,6 +495,12 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         HIPCHK(hipEventSynchronize(b->ev[3]));
         HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
         HIPCHK(hipEventElapsedTime(&tm->iter_ms, b->ev[1], b->ev[2]));
+        tm->dom_ms = 0.f;
+        for (int it = 0; it < I; it++) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, b->dom_ev[2 * it], b->dom_ev[2 * it + 1]));
+            tm->dom_ms += ms;
+        }
         tm->iter_launches = I;
         tm->fast_path = b->fast;
         tm->frames = b->total_frames;

@@ -184,8 +184,8 @@ class Batch:
     def run_timed(self):
         t = GomelTiming()
         check(_lib.lib().gomel_batch_run_timed(self._b, ctypes.byref(t)), "gomel_batch_run_timed")
-        return {"total_ms": t.total_ms, "iter_ms": t.iter_ms, "iter_launches": t.iter_launches, "fast_path": t.fast_path,
-                "frames": t.frames}
+        return {"total_ms": t.total_ms, "iter_ms": t.iter_ms, "dom_ms": t.dom_ms, "iter_launches": t.iter_launches,
+                "fast_path": t.fast_path, "frames": t.frames, "dom_kernel": "k_gl_fused" if t.fast_path else "k_gl_frames"}
 
     def sync(self):
         check(_lib.lib().gomel_batch_sync(self._b), "gomel_batch_sync")

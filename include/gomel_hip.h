@@ -64,7 +64,8 @@ typedef struct gomel_batch gomel_batch;   /* device-resident batch of utterances
 typedef struct gomel_timing {
     float total_ms;        /* mel->magnitude + x0 init + all iterations + finalize                        */
     float iter_ms;         /* the Griffin-Lim iteration launches only (sum over iterations)               */
-    int32_t iter_launches; /* number of dominant-kernel launches inside iter_ms                           */
+    float dom_ms;          /* the dominant kernel alone, summed over its launches (events around each)    */
+    int32_t iter_launches; /* number of dominant-kernel launches                                          */
     int32_t fast_path;     /* 1 = fused sliding-window kernel, 0 = generic frames + overlap-add kernels   */
     int64_t frames;        /* frames processed                                                            */
 } gomel_timing;

@@ -270,26 +270,54 @@ GL_DEV void clamp_pair(v2f& a, v2f& b, v2f w, float ma, float mb) {
     b = v2f{e.x + o.y, o.x - e.y};       // conj(E' - i O')
 }
 
-// The whole spectral step on a lane's 16 registers.  mag points at this frame's row of N/2 scaled magnitudes,
-// nyq is the scaled magnitude of bin N/2.  (mel/mel.go:98-108 in the real-FFT form, SURVEY Appendix A.)
-template <class G> GL_DEV void spectral_step(v2f (&v)[16], int t, const float* __restrict__ mag, float nyq, const v2f* __restrict__ wn) {
-    const bool is0 = (t == 0);
+// Target magnitudes a lane needs for one frame, loaded early so the HBM latency hides behind the forward FFT.
+struct MagRegs {
     float ma[8], mb[8];
-    v2f w[8];
+    float m0, mn;  // bins 0 and N/2 (lane 0 only)
+};
+template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restrict__ mag, const float* __restrict__ nyq) {
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int k = slot_bin<G>(t, s);
-        ma[s] = mag[k]; mb[s] = mag[G::C - k]; w[s] = wn[k];
+        m.ma[s] = mag[k];
+        m.mb[s] = mag[G::C - k];
     }
+    m.m0 = 0.f; m.mn = 0.f;
+    if (t == 0) { m.m0 = mag[0]; m.mn = nyq[0]; }
+}
+// The same eight W_N^{k_s} from ONE table value: k_s = t + B3*s and N/B3 = 16, so W_N^{k_s} = W_N^t * W_16^s (lane 0's
+// permuted slots get their constants).  Costs a few multiplies per frame, saves 14 registers in the fused kernel.
+template <class G> GL_DEV void make_wn(v2f (&w)[8], int t, v2f wt) {
+    constexpr double c16[8] = {1.0, kC1, kS2, kS1, 0.0, -kS1, -kS2, -kC1};
+    constexpr double s16[8] = {0.0, kS1, kS2, kC1, 1.0, kC1, kS2, kS1};
+    // W_32^{1,3,5,7} = cos/sin(pi m/16)
+    constexpr double c32[4] = {0.98078528040323044913, 0.83146961230254523708, 0.55557023301960222474, 0.19509032201612826785};
+    constexpr double s32[4] = {0.19509032201612826785, 0.55557023301960222474, 0.83146961230254523708, 0.98078528040323044913};
+    const bool is0 = (t == 0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        v2f g = twc<false>(wt, c16[s], s16[s]);  // wt * W_16^s
+        v2f z = s == 0 ? v2f{0.f, -1.f} : (s < 4 ? v2f{(float)c16[s], (float)-s16[s]} : v2f{(float)c32[s - 4], (float)-s32[s - 4]});
+        w[s] = is0 ? z : g;
+    }
+}
+template <class G> GL_DEV void load_wn(v2f (&w)[8], int t, const v2f* __restrict__ wn) {
+#pragma unroll
+    for (int s = 0; s < 8; s++) w[s] = wn[slot_bin<G>(t, s)];
+}
+
+// The whole spectral step on a lane's 16 registers (mel/mel.go:98-108 in the real-FFT form).
+template <class G> GL_DEV void spectral_apply(v2f (&v)[16], int t, const MagRegs& m, const v2f (&w)[8]) {
+    const bool is0 = (t == 0);
     v2f dc = v[0];
     lane0_permute<G>(v, is0);
 #pragma unroll
-    for (int s = 0; s < 8; s++) clamp_pair(v[s], v[15 - s], w[s], ma[s], mb[s]);
+    for (int s = 0; s < 8; s++) clamp_pair(v[s], v[15 - s], w[s], m.ma[s], m.mb[s]);
     if (is0) {
         // DC and Nyquist: X[0] = Re+Im, X[N/2] = Re-Im (real); Y = +-M; Z'[0] = (Y0+Yn) + i (Y0-Yn)
         float x0 = dc.x + dc.y, xn = dc.x - dc.y;
-        float y0 = x0 < 0.f ? -mag[0] : mag[0];
-        float yn = xn < 0.f ? -nyq : nyq;
+        float y0 = x0 < 0.f ? -m.m0 : m.m0;
+        float yn = xn < 0.f ? -m.mn : m.mn;
         dc = v2f{y0 + yn, y0 - yn};
     }
     lane0_unpermute<G>(v, is0, dc);

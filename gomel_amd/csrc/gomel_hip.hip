@@ -43,6 +43,7 @@ struct DevTables {
     const double* windowd; // [N]
     const BinRow* undo;    // [N/2]
     const BinRow* dom;     // [K]
+    const float* zeros;    // [N] zeros: target of "no tail here" loads in the fused kernel
 };
 
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
@@ -128,11 +129,14 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
 
     const v2f* xs = reinterpret_cast<const v2f*>(x + frame_xoff[frame]);  // hop and offsets are even: 8-byte aligned
     const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
-    v2f v[16], w[16];
+    v2f v[16], w[16], wn[8];
+    MagRegs mr;
+    load_mags<G>(mr, t, mag + frame * G::C, nyq + frame);
+    load_wn<G>(wn, t, tb.wn);
 #pragma unroll
     for (int j = 0; j < 16; j++) { w[j] = w2[t + G::T * j]; v[j] = xs[t + G::T * j] * w[j]; }
     fft_forward<G>(v, my, t, tw, sync);
-    spectral_step<G>(v, t, mag + frame * G::C, nyq[frame], tb.wn);
+    spectral_apply<G>(v, t, mr, wn);
     fft_inverse<G>(v, my, t, tw, sync);
     if (live) {
         v2f* ys = reinterpret_cast<v2f*>(yw + frame * N);
@@ -153,6 +157,145 @@ __global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, c
         for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
         xn[u.xoff + n] = acc;
     }
+}
+
+
+// =============================================================================================== fused path
+// One stream of T lanes walks a SEGMENT of G consecutive frames of one utterance.  With hop = SH*(N/16) the frame's
+// sample pairs sit in registers by "row" (row j = pairs t + T*j, N/16 samples), and moving to the next frame is a shift
+// by SH registers: SH new rows are loaded (hop samples), SH finished rows of the overlap-add are stored (hop samples).
+// So per frame-iteration the kernel reads hop*4 + (N/2+1)*4 bytes and writes hop*4 -- the algorithmic minimum.
+// Segment boundaries: a segment OWNS the samples [s0, s0 + G*hop) (the last one of an utterance: to the utterance's
+// end).  What its frames add beyond that (N - hop samples, the next segment's head) goes to a per-segment TAIL buffer;
+// whoever reads a head sample next iteration adds x + tail (two plain loads, deterministic, no atomics).
+struct SegDesc {
+    int64_t s0;       // offset of the segment's first sample in the x buffers
+    int64_t frame0;   // global index of its first frame (row of mag / nyq)
+    int32_t G;        // frames in the segment
+    int32_t has_prev; // not the first segment of its utterance -> add tail[seg-1] over the first 16-SH rows
+    int32_t has_next; // not the last -> rows >= G*SH belong to the next segment: read x + tail[seg], write tail[seg]
+    int32_t pad_;
+};
+
+constexpr int kFusedThreads = 256;
+
+template <int N, int SH>
+__global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __restrict__ x_in, const float* __restrict__ tail_in,
+                                                     float* __restrict__ x_out, float* __restrict__ tail_out,
+                                                     const SegDesc* __restrict__ segs, int n_segs, int g_max,
+                                                     const float* __restrict__ mag, const float* __restrict__ nyq, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = kFusedThreads / T, KEEP = 16 - SH, TAIL_PAIRS = KEEP * T;  // tail = (N - hop)/2 pairs
+    // LDS: per-stream exchange areas, then the tables every stream of the WG shares (TW1, TW2, window as pairs)
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
+    v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
+    v2f* tw2_l = tw1_l + G::TW1_N;
+    v2f* win_l = tw2_l + G::TW2_N;
+    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1[i];
+    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2[i];
+    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
+    __syncthreads();
+    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr};
+    #ifdef GOMEL_EXP_NOBAR
+    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+#else
+    auto sync = [] { __syncthreads(); };
+#endif
+
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    int seg = blockIdx.x * STREAMS + stream;
+    const bool live = seg < n_segs;
+    if (!live) seg = n_segs - 1;
+    const SegDesc d = segs[seg];
+    v2f* my = lds + stream * G::LDS_SLOTS;
+
+    const v2f* xin_p = reinterpret_cast<const v2f*>(x_in + d.s0) + t;      // row r -> xin_p[T*r]
+    v2f* xout_p = reinterpret_cast<v2f*>(x_out + d.s0) + t;
+    const v2f* tprev = reinterpret_cast<const v2f*>(tail_in) + (int64_t)(seg - 1) * TAIL_PAIRS + t;
+    const v2f* town = reinterpret_cast<const v2f*>(tail_in) + (int64_t)seg * TAIL_PAIRS + t;
+    v2f* tout = reinterpret_cast<v2f*>(tail_out) + (int64_t)seg * TAIL_PAIRS + t;
+    const int rows_owned = d.G * SH;  // rows >= this belong to the next segment's head
+    if constexpr (STREAMS > 1) {  // streams of one WG share the barriers: loop to the longest segment among them
+        __shared__ int g_sh[STREAMS];
+        if (t == 0) g_sh[stream] = live ? d.G : 0;
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < STREAMS; i++) m = max(m, g_sh[i]);
+        g_max = m;
+    } else {
+        g_max = d.G;
+    }
+
+    v2f xin[16], acc[16];
+    const v2f* wl = win_l + t;  // window pair of row j: wl[T*j]
+    const v2f wt = tb.wn[t];
+    // Tail terms are loaded unconditionally from a selected pointer (the tables' zero page when no tail applies), so the
+    // loads of a frame all go out together instead of one branch + vmcnt(0) each.
+    const v2f* zero_p = reinterpret_cast<const v2f*>(tb.zeros) + t;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const v2f* pp = (d.has_prev && j < KEEP) ? tprev + T * j : zero_p;
+        const v2f* pn = (d.has_next && j >= rows_owned) ? town + T * (j - rows_owned) : zero_p;
+        xin[j] = xin_p[T * j] + *pp + *pn;
+        acc[j] = v2f{0.f, 0.f};
+    }
+
+    for (int g = 0; g < g_max; g++) {
+        const bool active = live && g < d.G;
+        const int gg = g < d.G ? g : d.G - 1;
+        MagRegs mr;
+        load_mags<G>(mr, t, mag + (d.frame0 + gg) * G::C, nyq + d.frame0 + gg);
+        v2f v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = xin[j] * wl[T * j];
+        // slide the input window now: the next frame's SH new rows (hop samples) load behind the two FFTs
+#pragma unroll
+        for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];
+        const bool more = g + 1 < d.G;
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) {
+            const int row = (g + 1) * SH + KEEP + jj;
+            const v2f* px = more ? xin_p + T * row : zero_p;
+            const v2f* pn = (more && d.has_next && row >= rows_owned) ? town + T * (row - rows_owned) : zero_p;
+            xin[KEEP + jj] = *px + *pn;
+        }
+        fft_forward<G>(v, my, t, tw, sync);
+        {
+            v2f wn[8];
+            make_wn<G>(wn, t, wt);
+            spectral_apply<G>(v, t, mr, wn);
+        }
+        fft_inverse<G>(v, my, t, tw, sync);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[j] += v[j] * wl[T * j];
+#pragma unroll
+            for (int j = 0; j < SH; j++) xout_p[T * (g * SH + j)] = acc[j];   // rows finished by this frame
+            if (g == d.G - 1) {
+                // what is left belongs past the owned range: next segment's head (tail buffer) or the utterance's end
+#pragma unroll
+                for (int j = 0; j < KEEP; j++) {
+                    if (d.has_next) tout[T * j] = acc[SH + j];
+                    else xout_p[T * (rows_owned + j)] = acc[SH + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) acc[j] = acc[j + SH];
+#pragma unroll
+            for (int jj = 0; jj < SH; jj++) acc[KEEP + jj] = v2f{0.f, 0.f};
+        }
+    }
+}
+
+// out += tails (fp64), after k_finalize has converted the owned samples
+__global__ __launch_bounds__(256) void k_add_tails(const SegDesc* __restrict__ segs, const float* __restrict__ tail, double* __restrict__ out,
+                                                   int tail_len, int hop) {
+    const SegDesc d = segs[blockIdx.x];
+    if (!d.has_next) return;
+    double* o = out + d.s0 + (int64_t)d.G * hop;
+    const float* tp = tail + (int64_t)blockIdx.x * tail_len;
+    for (int i = threadIdx.x; i < tail_len; i += blockDim.x) o[i] += (double)tp[i];
 }
 
 // =============================================================================================== test hooks: plain rfft / irfft
@@ -342,8 +485,8 @@ static int upload_tables(gomel_handle* h) {
     auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     size_t o_win = carve(N * 4), o_tw1 = carve(C * 8), o_tw2 = carve(R2 * 8 * 8), o_wn = carve(C * 8);
     size_t o_tw1d = carve(C * 16), o_tw2d = carve(R2 * 8 * 16), o_wnd = carve(C * 16), o_wind = carve(N * 8);
-    size_t o_undo = carve(C * sizeof(BinRow)), o_dom = carve(K * sizeof(BinRow));
-    std::vector<char> host(off);
+    size_t o_undo = carve(C * sizeof(BinRow)), o_dom = carve(K * sizeof(BinRow)), o_zero = carve(N * 4);
+    std::vector<char> host(off, 0);
     memcpy(&host[o_win], wf.data(), N * 4);
     memcpy(&host[o_tw1], tw1.data(), C * 8); memcpy(&host[o_tw2], tw2.data(), R2 * 8 * 8); memcpy(&host[o_wn], wn.data(), C * 8);
     memcpy(&host[o_tw1d], tw1d.data(), C * 16); memcpy(&host[o_tw2d], tw2d.data(), R2 * 8 * 16); memcpy(&host[o_wnd], wnd.data(), C * 16);
@@ -357,6 +500,7 @@ static int upload_tables(gomel_handle* h) {
     h->dt.tw1d = (const v2d*)(d + o_tw1d); h->dt.tw2d = (const v2d*)(d + o_tw2d); h->dt.wnd = (const v2d*)(d + o_wnd);
     h->dt.windowd = (const double*)(d + o_wind);
     h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
+    h->dt.zeros = (const float*)(d + o_zero);
     return GOMEL_OK;
 }
 
@@ -430,21 +574,79 @@ struct gomel_batch {
     UttDesc* d_utts = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> dom_ev;  // 2 per iteration, created on the first timed run
+    // fused path
+    std::vector<SegDesc> segs;
+    SegDesc* d_segs = nullptr;
+    float* d_tail[2] = {nullptr, nullptr};  // [n_segs][N - hop]
+    int g_max = 0;
 };
 
 static void batch_free(gomel_batch* b) {
     if (!b) return;
     hipSetDevice(b->h->device);
-    void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts};
+    void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
+                    b->d_segs, b->d_tail[0], b->d_tail[1]};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
     delete b;
 }
 
-static bool fused_applicable(const gomel_config& c) {
-    (void)c;
-    return false;  // the fused sliding-window kernel is added in gl_fused (see below)
+// The fused kernel needs hop = SH * (N/16) with SH in the instantiated set.
+static int fused_shift(const gomel_config& c) {
+    const int row = c.resolut / 16;
+    if (c.window % row) return 0;
+    const int sh = c.window / row;
+    return (sh == 1 || sh == 2 || sh == 4 || sh == 5 || sh == 8) ? sh : 0;
+}
+static bool fused_applicable(const gomel_config& c) { return fused_shift(c) != 0; }
+
+static void plan_segments(gomel_batch* b) {
+    const gomel_config& c = b->h->cfg;
+    const int sh = fused_shift(c), keep = 16 - sh, gmin = (keep + sh - 1) / sh;
+    int gt = (int)std::min<int64_t>(std::max<int64_t>(b->total_frames / 4096, gmin), 64);
+    if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) gt = std::max(v, gmin); }  // tuning knob
+    b->segs.clear();
+    b->g_max = 0;
+    for (const UttDesc& u : b->utts) {
+        int nseg = std::max(1, (u.frames + gt / 2) / gt);
+        while (nseg > 1 && u.frames / nseg < gmin) nseg--;
+        const int base = u.frames / nseg, rem = u.frames % nseg;
+        int f0 = 0;
+        for (int s = 0; s < nseg; s++) {
+            SegDesc d;
+            d.G = base + (s < rem ? 1 : 0);
+            d.s0 = u.xoff + (int64_t)f0 * c.window;
+            d.frame0 = u.fbase + f0;
+            d.has_prev = s > 0; d.has_next = s + 1 < nseg; d.pad_ = 0;
+            b->segs.push_back(d);
+            b->g_max = std::max(b->g_max, d.G);
+            f0 += d.G;
+        }
+    }
+}
+
+template <int N, int SH> static void launch_fused_t(gomel_batch* b, int cur) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = kFusedThreads / G::T;
+    const int n = (int)b->segs.size();
+    hipLaunchKernelGGL((k_gl_fused<N, SH>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], b->d_tail[cur],
+                       b->d_x[cur ^ 1], b->d_tail[cur ^ 1], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, b->h->dt);
+}
+template <int N> static void launch_fused_n(gomel_batch* b, int cur, int sh) {
+    switch (sh) {
+        case 1: launch_fused_t<N, 1>(b, cur); break;
+        case 2: launch_fused_t<N, 2>(b, cur); break;
+        case 4: launch_fused_t<N, 4>(b, cur); break;
+        case 5: launch_fused_t<N, 5>(b, cur); break;
+        default: launch_fused_t<N, 8>(b, cur); break;
+    }
+}
+static void launch_fused(gomel_batch* b, int cur) {
+    const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
+    if (N == 4096) launch_fused_n<4096>(b, cur, sh);
+    else if (N == 2048) launch_fused_n<2048>(b, cur, sh);
+    else launch_fused_n<1024>(b, cur, sh);
 }
 
 template <int N> static void launch_frames(gomel_batch* b, const float* x) {
@@ -476,18 +678,22 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
+        const size_t tail_bytes = b->segs.size() * (size_t)(N - c.window) * 4;
+        if (b->fast) HIPCHK(hipMemsetAsync(b->d_tail[0], 0, tail_bytes, s));  // x0 has no tail contributions
         for (int it = 0; it < I; it++) {
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
-            if (N == 4096) launch_frames<4096>(b, b->d_x[cur]);
+            if (b->fast) launch_fused(b, cur);
+            else if (N == 4096) launch_frames<4096>(b, b->d_x[cur]);
             else if (N == 2048) launch_frames<2048>(b, b->d_x[cur]);
             else launch_frames<1024>(b, b->d_x[cur]);
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
-            hipLaunchKernelGGL(k_ola, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
+            if (!b->fast) hipLaunchKernelGGL(k_ola, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
             cur ^= 1;
         }
         if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
         const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
         hipLaunchKernelGGL(k_finalize, dim3(gf), dim3(256), 0, s, b->d_x[cur], b->d_out, b->total_len);
+        if (b->fast) hipLaunchKernelGGL(k_add_tails, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], b->d_out, N - c.window, c.window);
     }
     HIPCHK(hipGetLastError());
     if (tm) {
@@ -701,11 +907,18 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
         alloc((void**)&b->d_nyq, (size_t)b->total_frames * 4);
         alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
         alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
-        alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+        if (!b->fast) alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
         if (!b->fast) alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4);
+        if (b->fast) {
+            plan_segments(b);
+            alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
+            alloc((void**)&b->d_tail[0], b->segs.size() * (size_t)(N - hop) * 4);
+            alloc((void**)&b->d_tail[1], b->segs.size() * (size_t)(N - hop) * 4);
+            if (!rc && hipMemcpy(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+        }
     }
     for (auto& e : b->ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = GOMEL_ERR_HIP;
-    if (!rc && I > 0) {
+    if (!rc && I > 0 && !b->fast) {
         std::vector<int64_t> fx((size_t)b->total_frames);
         for (size_t u = 0; u < n_utt; u++)
             for (int f = 0; f < b->utts[u].frames; f++) fx[(size_t)b->utts[u].fbase + f] = b->utts[u].xoff + (int64_t)f * hop;

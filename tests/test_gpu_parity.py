@@ -22,11 +22,14 @@ def rms(a):
     return float(np.sqrt(np.mean(np.square(a))))
 
 
-def make_mel(geom, iters, **kw):
+def make_mel(geom, iters, path=0, **kw):
+    """path: 0 = library's choice (fused kernel when hop = SH*N/16), 1 = force the generic kernels."""
     import gomel_amd
     m = gomel_amd.NewMel()
     for k, v in dict(GEOMS[geom], GriffinLimIterations=iters, **kw).items():
         setattr(m, k, v)
+    if path:
+        m.engine().set_path(path)
     return m
 
 
@@ -64,10 +67,13 @@ def test_target_magnitudes(oracle, geom):
     assert np.max(np.abs(got - want) / (np.abs(want) + 1e-30)) < 2e-7
 
 
-@pytest.mark.parametrize("geom,frames", [("T", 4), ("T", 9), ("S", 8), ("S", 3), ("D", 6), ("T", 1)])
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("geom,frames", [("T", 4), ("T", 9), ("S", 8), ("S", 3), ("D", 6), ("T", 1), ("T", 40), ("S", 70), ("D", 33)])
 @pytest.mark.parametrize("iters", [0, 1, 2, 60])
-def test_from_mel_matches_oracle(oracle, geom, frames, iters):
-    m = make_mel(geom, iters)
+def test_from_mel_matches_oracle(oracle, geom, frames, iters, path):
+    if iters == 60 and frames > 40:
+        iters = 20   # keep the oracle side of the long cases to seconds
+    m = make_mel(geom, iters, path)
     cfg = ocfg(oracle, geom, iters)
     mel = oracle.random_logmel(frames, cfg.NumMels, seed=100 + frames)
     L = oracle.out_len(cfg, len(mel))
@@ -95,8 +101,9 @@ def test_seed_generator_matches_documented_splitmix(oracle):
     assert rms(a - b) < 1e-6
 
 
-def test_ragged_batch_equals_single_calls(oracle):
-    m = make_mel("S", 3)
+@pytest.mark.parametrize("path", [0, 1])
+def test_ragged_batch_equals_single_calls(oracle, path):
+    m = make_mel("S", 3, path)
     cfg = ocfg(oracle, "S", 3)
     fr = [3, 17, 1, 8, 40]
     mels = [oracle.random_logmel(f, 80, seed=i) for i, f in enumerate(fr)]
@@ -138,3 +145,36 @@ def test_error_statuses():
     with pytest.raises(gomel_amd.GomelError) as ei:
         m.FromMel(np.zeros((192, 2)))
     assert ei.value.status == 2
+
+
+def test_fused_segments_are_invisible(oracle, monkeypatch):
+    """The fused kernel splits utterances into segments of consecutive frames; any split must give the generic path's
+    answer (segment tails are exchanged through the tail buffers).  GOMEL_SEG_FRAMES is the library's tuning knob."""
+    cfg = ocfg(oracle, "T", 4)
+    fr = [37, 5, 64, 3, 11]
+    mels = [oracle.random_logmel(f, 192, seed=20 + i) for i, f in enumerate(fr)]
+    x0s = [oracle.x0_splitmix(i, oracle.out_len(cfg, len(mm))) for i, mm in enumerate(mels)]
+    ref = make_mel("T", 4, path=1).FromMelBatch([mm.copy() for mm in mels], x0s)
+    for seg in ("3", "4", "7", "64"):
+        monkeypatch.setenv("GOMEL_SEG_FRAMES", seg)
+        got = make_mel("T", 4).FromMelBatch([mm.copy() for mm in mels], x0s)
+        for a, b in zip(got, ref):
+            assert rms(a - b) < 2e-6, seg
+    want = oracle.from_mel(cfg, mels[0].copy(), x0s[0])
+    assert rms(ref[0] - want) < RMS_TOL
+
+
+@pytest.mark.parametrize("hop", [256, 512, 1024, 2048, 1280, 768, 100])
+def test_hops_fused_and_generic(oracle, hop):
+    """hop = SH*N/16 with SH in {1,2,4,5,8} takes the fused kernel, anything else (768 = 3 rows, 100) the generic one."""
+    kw = dict(NumMels=192, MelFmax=16000.0, Window=hop, Resolut=4096, GriffinLimIterations=3)
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    for k, v in kw.items():
+        setattr(m, k, v)
+    cfg = oracle.MelConfig(**kw)
+    mel = oracle.random_logmel(21, 192, seed=hop)
+    x0 = oracle.x0_splitmix(hop, oracle.out_len(cfg, len(mel)))
+    want = oracle.from_mel(cfg, mel.copy(), x0)
+    got = m.FromMel(mel.copy(), x0=x0)
+    assert rms(got - want) < RMS_TOL

@@ -298,6 +298,72 @@ __global__ __launch_bounds__(256) void k_add_tails(const SegDesc* __restrict__ s
     for (int i = threadIdx.x; i < tail_len; i += blockDim.x) o[i] += (double)tp[i];
 }
 
+
+// =============================================================================================== ToMel (forward path), fp64
+// gossp STFT (window + fft.FFTReal, mel/mel.go:52) -> |S[j]|, j in [0, N/2]  (mel/mel.go:55-63 pairs |S[j]| with
+// |S[N-1-j]| = |S[j+1]|, so one array of N/2+1 magnitudes serves both channels).  fp64 because ln() of bins near the
+// 1e-5 floor needs more dynamic range than an fp32 FFT keeps.
+template <int N>
+__global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wave, double* __restrict__ smag, int64_t n_frames, int hop, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    auto sync = [] { __syncthreads(); };
+    const double* xs = wave + frame * hop;
+    v2d v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = 2 * (t + G::T * j);
+        v[j] = v2d{xs[p] * tb.windowd[p], xs[p + 1] * tb.windowd[p + 1]};
+    }
+    fft_forward<G>(v, my, t, tw, sync);
+    if (!live) return;
+    double* out = smag + frame * (G::C + 1);
+    const bool is0 = (t == 0);
+    const v2d dc = v[0];
+    if (is0) {  // same slot permutation as lane0_permute, fp64
+        v2d a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[i] = v[i]; b[i] = v[8 + i]; }
+        v[0] = a[4]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        v[8] = b[4]; v[9] = b[5]; v[10] = b[6]; v[11] = b[7]; v[12] = a[5]; v[13] = a[6]; v[14] = a[7]; v[15] = a[4];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        const v2d a = v[s], b = v[15 - s], wk = tb.wnd[k];
+        const v2d bc = v2d{b.x, -b.y};
+        const v2d p = a + bc, d = a - bc;
+        const v2d q = cmul(wk, v2d{d.y, -d.x});
+        const v2d xk = p + q, xc = p - q;  // 2 X[k], 2 conj(X[C-k])
+        out[k] = 0.5 * hypot(xk.x, xk.y);
+        out[G::C - k] = 0.5 * hypot(xc.x, xc.y);
+    }
+    if (is0) { out[0] = fabs(dc.x + dc.y); out[G::C] = fabs(dc.x - dc.y); }
+}
+
+// domel (mel/impl.go:310-345) + spectral_normalize (mel/impl.go:410-419): one block per frame, one thread per band.
+__global__ __launch_bounds__(256) void k_domel_log(const double* __restrict__ smag, const BinRow* __restrict__ dom, double* __restrict__ out,
+                                                   int K, int H) {
+    const int64_t f = blockIdx.x;
+    const double* m = smag + f * (H + 1);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const BinRow r = dom[i];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            double v = apply_row(r, m + c);  // channel 1 is the same spectrum one bin up: |S[N-1-j]| = |S[j+1]|
+            if (v < 1e-5) v = 1e-5;
+            out[(f * K + i) * 2 + c] = log(v);
+        }
+    }
+}
+
 // =============================================================================================== test hooks: plain rfft / irfft
 template <int N>
 __global__ __launch_bounds__(128) void k_rfft(const float* __restrict__ frames, float* __restrict__ spec, int64_t n_frames, DevTables tb) {
@@ -382,6 +448,7 @@ static thread_local int g_last_hip = 0;
 struct TableHeader {
     uint32_t magic, version;
     int32_t n, hop, k, hann_periodic;
+    int32_t dom_status, pad_;
     double fmin, fmax;
 };
 static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
@@ -392,6 +459,7 @@ struct gomel_handle {
     hipStream_t stream = nullptr;
     std::mutex mu;
     int path_mode = 0;
+    int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
     std::vector<double> window;   // [N]
     std::vector<BinRow> undo;     // [N/2]
     std::vector<BinRow> dom;      // [K]
@@ -504,10 +572,6 @@ static int upload_tables(gomel_handle* h) {
     return GOMEL_OK;
 }
 
-static int dom_status_of(const gomel_handle* h) {
-    for (const BinRow& r : h->dom) if (r.mode == 2 && r.lo == 0 && r.hi == 0 && r.div == 1 && &r != &h->dom[0]) return GOMEL_ERR_TABLE_RANGE;
-    return GOMEL_OK;
-}
 
 static int create_common(const gomel_config* cfg, const void* blob, size_t blob_bytes, gomel_handle** out) {
     if (!cfg || !out) return GOMEL_ERR_NULL;
@@ -536,12 +600,12 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         h->undo.resize(C); memcpy(h->undo.data(), p, (size_t)C * sizeof(BinRow)); p += (size_t)C * sizeof(BinRow);
         h->dom.resize(K); memcpy(h->dom.data(), p, (size_t)K * sizeof(BinRow));
         h->cfg.hann_periodic = th.hann_periodic;
+        h->dom_status = th.dom_status;
     } else {
         h->window.resize(N);
         const double arg = 2.0 * M_PI / (double)(cfg->hann_periodic ? N : N - 1);  // gossp window.CreateHanning
         for (int i = 0; i < N; i++) h->window[i] = 0.5 - 0.5 * std::cos(arg * (double)i);
-        int dom_rc = GOMEL_OK;
-        rc = build_mel_tables(*cfg, h->undo, h->dom, &dom_rc);
+        rc = build_mel_tables(*cfg, h->undo, h->dom, &h->dom_status);
         if (rc) { delete h; return rc; }
     }
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -798,7 +862,8 @@ size_t gomel_tables_bytes(const gomel_handle* h) {
 int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap) {
     if (!h || !blob) return GOMEL_ERR_NULL;
     if (cap < gomel_tables_bytes(h)) return GOMEL_ERR_BUFFER_TOO_SMALL;
-    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, h->cfg.resolut, h->cfg.window, h->cfg.num_mels, h->cfg.hann_periodic, h->cfg.mel_fmin, h->cfg.mel_fmax};
+    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, h->cfg.resolut, h->cfg.window, h->cfg.num_mels, h->cfg.hann_periodic, h->dom_status, 0,
+                   h->cfg.mel_fmin, h->cfg.mel_fmax};
     char* p = (char*)blob;
     memcpy(p, &th, sizeof th); p += sizeof th;
     memcpy(p, h->window.data(), h->window.size() * 8); p += h->window.size() * 8;
@@ -1078,8 +1143,36 @@ size_t gomel_to_mel_pairs(const gomel_config* c, size_t n) {
 }
 
 int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
-    (void)h; (void)wave; (void)n; (void)out_pairs; (void)cap_pairs; (void)n_pairs;
-    return GOMEL_ERR_BAD_CONFIG;  // implemented in the ToMel step
+    if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
+    const gomel_config& c = h->cfg;
+    const int N = c.resolut, H = N / 2, K = c.num_mels, hop = c.window;
+    if (n == 0) return GOMEL_ERR_EMPTY;
+    if (h->dom_status) return h->dom_status;
+    const size_t P = gomel_pad_len(n, hop);                                   // pad, mel/impl.go:429-455
+    if (P < (size_t)N) return GOMEL_ERR_TOO_SHORT;
+    const size_t pairs = gomel_to_mel_pairs(&c, n), F = pairs / (size_t)K;    // gossp NumFrames
+    if (cap_pairs < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
+    int rc = GOMEL_OK;
+    if (hipMalloc((void**)&d_wave, P * 8) != hipSuccess || hipMalloc((void**)&d_smag, F * (size_t)(H + 1) * 8) != hipSuccess ||
+        hipMalloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
+                hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
+    if (!rc) {
+        if (N == 4096) hipLaunchKernelGGL(k_stft_mag<4096>, dim3((unsigned)((F + 0) / 1)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt);
+        else if (N == 2048) hipLaunchKernelGGL(k_stft_mag<2048>, dim3((unsigned)((F + 1) / 2)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt);
+        else hipLaunchKernelGGL(k_stft_mag<1024>, dim3((unsigned)((F + 3) / 4)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt);
+        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)F), dim3(256), 0, h->stream, d_smag, h->dt.dom, d_out, K, H);
+        if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    }
+    if (d_wave) hipFree(d_wave);
+    if (d_smag) hipFree(d_smag);
+    if (d_out) hipFree(d_out);
+    if (!rc && n_pairs) *n_pairs = pairs;
+    return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,114 @@
+"""CPU tests of the drop-in boundary: libgomel_hip.so loads, exports every symbol include/gomel_hip.h declares, and its
+host-only entry points behave (no compute calls: there is no GPU here and no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from gomel_amd import build, _lib
+    build.build()
+    return _lib.lib()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gomel_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gomel_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from gomel_amd import _lib
+    names = header_functions()
+    assert len(names) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libgomel_hip.so lacks %s" % n
+    assert sorted(_lib.SYMBOLS) == names          # the ctypes table and the header agree, nothing more, nothing less
+
+
+def test_header_cites_reference_interfaces():
+    src = open(os.path.join(ROOT, "include", "gomel_hip.h")).read()
+    for cite in ("mel/mel.go:142-152", "mel/mel.go:46-74", "mel/mel.go:30-41", "mel/mel.go:80", "mel/impl.go:429-479", "mel/mel.go:50,145"):
+        assert cite in src
+
+
+def test_default_config_is_newmel(L):
+    from gomel_amd._lib import GomelConfig
+    c = GomelConfig()
+    assert L.gomel_default_config(ctypes.byref(c)) == 0
+    assert (c.num_mels, c.window, c.resolut, c.griffin_lim_iterations) == (160, 256, 2048, 2)     # mel/mel.go:30-41
+    assert (c.mel_fmin, c.mel_fmax, c.tune_mul, c.tune_add) == (0.0, 8000.0, 1.0, 0.0)
+    assert L.gomel_abi_version() == 1
+
+
+def test_length_helpers_match_oracle(L, oracle):
+    from gomel_amd._lib import GomelConfig
+    c = GomelConfig()
+    L.gomel_default_config(ctypes.byref(c))
+    c.num_mels, c.window, c.resolut = 192, 1280, 4096
+    assert L.gomel_out_len(ctypes.byref(c), 342 * 192) == 440576        # 10 s @44.1 kHz
+    assert L.gomel_out_len(ctypes.byref(c), 183 * 80) == 0               # not a multiple of NumMels
+    assert L.gomel_out_len(ctypes.byref(c), 0) == 0
+    for n, hop in [(441000, 1280), (19200, 1280), (19201, 1280), (100, 256), (3840, 256), (1, 2)]:
+        want = len(oracle.pad(np.zeros(n), hop))
+        assert L.gomel_pad_len(n, hop) == want
+        assert L.gomel_is_padded(n, want, hop) == 1 and L.gomel_is_padded(n, want + 1, hop) == 0
+        assert bool(L.gomel_is_padded(n, n, hop)) == oracle.is_padded(n, n, hop)
+    cfg = oracle.towav_config()
+    assert L.gomel_to_mel_pairs(ctypes.byref(c), 441000) == 342 * 192
+    assert L.gomel_to_mel_pairs(ctypes.byref(c), 22050) == oracle.num_frames(len(oracle.pad(np.zeros(22050), 1280)), 4096, 1280) * cfg.NumMels
+
+
+def test_no_device_means_error_not_fallback(L):
+    """On a machine without a GPU the library must refuse, never compute on the CPU."""
+    from gomel_amd._lib import GomelConfig
+    if L.gomel_device_count() > 0:
+        pytest.skip("a GPU is present")
+    c = GomelConfig()
+    L.gomel_default_config(ctypes.byref(c))
+    h = ctypes.c_void_p()
+    assert L.gomel_create(ctypes.byref(c), ctypes.byref(h)) == 9 and not h      # GOMEL_ERR_NO_DEVICE
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    with pytest.raises(gomel_amd.GomelError) as ei:
+        m.FromMel(np.zeros((160, 2)))
+    assert ei.value.status == 9
+
+
+def test_config_validation_statuses(L):
+    from gomel_amd._lib import GomelConfig
+    h = ctypes.c_void_p()
+    for field, val, status in [("resolut", 3000, 2), ("resolut", 512, 2), ("num_mels", 0, 1), ("window", 0, 1), ("window", 255, 1),
+                               ("tune_mul", 0.0, 1), ("mel_fmax", 0.0, 1), ("griffin_lim_iterations", -1, 1)]:
+        c = GomelConfig()
+        L.gomel_default_config(ctypes.byref(c))
+        setattr(c, field, val)
+        assert L.gomel_create(ctypes.byref(c), ctypes.byref(h)) == status, field
+    assert L.gomel_create(None, ctypes.byref(h)) == 7
+    assert b"NumMels" in L.gomel_strerror(3) and L.gomel_strerror(0) == b"ok" and L.gomel_strerror(999) == b"unknown status"
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gomel_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "gomel_oracle" not in txt and "oracle_c" not in txt and "libgomel_oracle" not in txt, f
+
+
+def test_newmel_mirror_fields():
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    assert (m.NumMels, m.MelFmin, m.MelFmax, m.TuneMul, m.TuneAdd, m.Window, m.Resolut, m.GriffinLimIterations) == (160, 0, 8000, 1, 0, 256, 2048, 2)
+    assert m.YReverse is False and m.VolumeBoost == 0 and m.SampleRate == 0
+    assert str(gomel_amd.ErrFileNotLoaded()) == "wavNotLoaded"           # mel/mel.go:43
+    with pytest.raises(TypeError):
+        m.FromMel([[0.0, 0.0]] * 160)                                     # must be an in-place-modifiable float64 array

@@ -61,14 +61,23 @@ template <class V> struct Twiddles {
 };
 
 // ---------------------------------------------------------------------------------------------- complex helpers
-template <class V> GL_DEV V cmul(V a, V b) { return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-template <class V> GL_DEV V cmulc(V a, V b) { return V{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }  // a * conj(b)
-template <bool INV, class V> GL_DEV V mul_mi(V a) { return INV ? V{-a.y, a.x} : V{a.y, -a.x}; }  // * (-i) fwd, (+i) inv
+// Written in explicit 2-lane vector form so that hipcc emits ONE packed op per line and folds the lane swaps /
+// broadcasts / negations into VOP3P op_sel / neg modifiers (a complex multiply = v_pk_mul + v_pk_fma).  The scalar-form
+// spelling gets SLP-packed into 3 packed ops + a v_mov with half the lanes thrown away.
+#define GL_XX(v) __builtin_shufflevector(v, v, 0, 0)
+#define GL_YY(v) __builtin_shufflevector(v, v, 1, 1)
+#define GL_YX(v) __builtin_shufflevector(v, v, 1, 0)
+template <class V> GL_DEV V vfma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
+template <class V> GL_DEV V rot_mi(V a) { V s = GL_YX(a); return V{s.x, -s.y}; }  // a * (-i) = ( a.y, -a.x)
+template <class V> GL_DEV V rot_pi(V a) { V s = GL_YX(a); return V{-s.x, s.y}; }  // a * (+i) = (-a.y,  a.x)
+template <class V> GL_DEV V cmul(V a, V b) { return vfma(rot_pi(a), GL_YY(b), a * GL_XX(b)); }   // a * b
+template <class V> GL_DEV V cmulc(V a, V b) { return vfma(rot_mi(a), GL_YY(b), a * GL_XX(b)); }  // a * conj(b)
+template <bool INV, class V> GL_DEV V mul_mi(V a) { return INV ? rot_pi(a) : rot_mi(a); }  // * (-i) fwd, (+i) inv
 // a * (c - i s) forward, a * (c + i s) inverse
 template <bool INV, class V> GL_DEV V twc(V a, double c_, double s_) {
     typedef typename ScalarOf<V>::type S;
-    const S c = (S)c_, s = (S)s_;
-    return INV ? V{a.x * c - a.y * s, a.y * c + a.x * s} : V{a.x * c + a.y * s, a.y * c - a.x * s};
+    const V cc = V{(S)c_, (S)c_}, ss = V{(S)s_, (S)s_};
+    return vfma(INV ? rot_pi(a) : rot_mi(a), ss, a * cc);
 }
 
 constexpr double kS2 = 0.70710678118654752440;  // sqrt(1/2)
@@ -128,17 +137,24 @@ template <bool INV, int R, int S, class V> GL_DEV void dftR(V* v) {
 // `lds` is this stream's exchange area (G::LDS_SLOTS slots).  SYNC() is a barrier covering the stream's lanes.
 template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
     // ---- pass 1: NB1 radix-R1 butterflies; butterfly u holds registers j = u + NB1*m, t1 = t + T*u
+    // The pass's twiddles are read into registers BEFORE any exchange store: table and exchange area live in the same
+    // LDS array, so a twiddle read placed after a store could not be hoisted above it (one LDS round trip per element).
+    V w1[16];
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++)
+#pragma unroll
+        for (int q = 1; q < G::R1; q++) w1[u + G::NB1 * q] = tw.tw1[q * G::C1 + t + G::T * u];
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<false, G::R1, G::NB1>(&v[u]);
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++)
+#pragma unroll
+        for (int q = 1; q < G::R1; q++) v[u + G::NB1 * q] = cmul(v[u + G::NB1 * q], w1[u + G::NB1 * q]);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
 #pragma unroll
-        for (int q = 0; q < G::R1; q++) {
-            V val = v[u + G::NB1 * q];
-            if (q) val = cmul(val, tw.tw1[q * G::C1 + t1]);
-            lds[q * G::SA + t1] = val;
-        }
+        for (int q = 0; q < G::R1; q++) lds[q * G::SA + t1] = v[u + G::NB1 * q];
     }
     sync();
     // ---- pass 2: NB2 radix-R2 butterflies beta = t + T*u2 -> (q1 = beta % R1, t2 = beta / R1)
@@ -149,16 +165,24 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
         for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * G::SA + t2 + 8 * m];
     }
     sync();
+    V w2[16];
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) {
+        const int t2 = (t + G::T * u) / G::R1;
+#pragma unroll
+        for (int q = 1; q < G::R2; q++) w2[u * G::R2 + q] = tw.tw2[q * 8 + t2];
+    }
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) {
+        dftR<false, G::R2, 1>(&v[u * G::R2]);
+#pragma unroll
+        for (int q = 1; q < G::R2; q++) v[u * G::R2 + q] = cmul(v[u * G::R2 + q], w2[u * G::R2 + q]);
+    }
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
-        dftR<false, G::R2, 1>(&v[u * G::R2]);
 #pragma unroll
-        for (int q = 0; q < G::R2; q++) {
-            V val = v[u * G::R2 + q];
-            if (q) val = cmul(val, tw.tw2[q * 8 + t2]);
-            lds[t2 * G::SB + q1 + G::R1 * q] = val;
-        }
+        for (int q = 0; q < G::R2; q++) lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
     }
     sync();
     // ---- pass 3: the mirrored radix-8 butterflies bA, bB
@@ -259,33 +283,59 @@ GL_DEV void clamp_pair(v2f& a, v2f& b, v2f w, float ma, float mb) {
     v2f bc = v2f{b.x, -b.y};
     v2f p = a + bc;                      // 2 E_k
     v2f d = a - bc;                      // 2 i O_k
-    v2f q = cmul(w, v2f{d.y, -d.x});     // 2 w O_k
+    v2f q = cmul(w, rot_mi(d));          // 2 w O_k
     v2f xk = p + q;                      // 2 X[k]
     v2f xc = p - q;                      // 2 conj(X[C-k])
-    v2f u = unit_phase(xk) * ma;                    // Y[k]
-    v2f vv = unit_phase(xc) * mb;                   // conj(Y[C-k])  (conj of a unit phasor times a real)
+    v2f u = unit_phase(xk) * ma;         // Y[k]
+    v2f vv = unit_phase(xc) * mb;        // conj(Y[C-k])  (conj of a unit phasor times a real)
     v2f e = u + vv;                      // 2 E'
     v2f o = cmulc(u - vv, w);            // 2 O' = conj(w) (U - V)
-    a = v2f{e.x - o.y, e.y + o.x};       // E' + i O'
-    b = v2f{e.x + o.y, o.x - e.y};       // conj(E' - i O')
+    v2f io = rot_pi(o);                  // i O'
+    a = e + io;                          // E' + i O'
+    v2f t = e - io;                      // E' - i O'
+    b = v2f{t.x, -t.y};                  // conj(E' - i O')
 }
 
-// Target magnitudes a lane needs for one frame, loaded early so the HBM latency hides behind the forward FFT.
+// Target magnitudes a lane needs for one frame.  A frame's row of N/2 magnitudes is stored in LANE-SLOT order
+// (mag_slot_index below): entry e of lane t sits at float (e/4 * T + t) * 4 + e%4, e < 8: mag[k_e(t)], e >= 8:
+// mag[C - k_{e-8}(t)] -- so a lane fetches everything with four coalesced 16-byte loads off one base pointer, issued
+// early so the HBM latency hides behind the forward FFT.  Lane 0's duplicate entry (slot 0 pairs bin C/2 with itself)
+// carries bin 0 (DC) instead.
 struct MagRegs {
     float ma[8], mb[8];
     float m0, mn;  // bins 0 and N/2 (lane 0 only)
 };
-template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restrict__ mag, const float* __restrict__ nyq) {
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        const int k = slot_bin<G>(t, s);
-        m.ma[s] = mag[k];
-        m.mb[s] = mag[G::C - k];
-    }
-    m.m0 = 0.f; m.mn = 0.f;
-    if (t == 0) { m.m0 = mag[0]; m.mn = nyq[0]; }
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// natural bin k in [0, C)  ->  float index inside the permuted row
+template <class G> __host__ __device__ inline int mag_slot_index(int k) {
+    const int r = k % G::B3, s = k / G::B3;
+    int t, e;
+    if (r == 0) { t = 0; e = (k == 0) ? 8 : (s == 4 ? 0 : (s < 4 ? s : 8 + (8 - s))); }
+    else if (r == G::B3 / 2) { t = 0; e = (s < 4) ? 4 + s : 8 + 4 + (7 - s); }
+    else if (r < G::B3 / 2) { t = r; e = s; }
+    else { t = G::B3 - r; e = 8 + (7 - s); }
+    return ((e / 4) * G::T + t) * 4 + (e % 4);
 }
-// The same eight W_N^{k_s} from ONE table value: k_s = t + B3*s and N/B3 = 16, so W_N^{k_s} = W_N^t * W_16^s (lane 0's
+
+template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restrict__ mag_row, const float* __restrict__ nyq) {
+    const v4f* r4 = reinterpret_cast<const v4f*>(mag_row);
+    v4f c0 = r4[t], c1 = r4[G::T + t], c2 = r4[2 * G::T + t], c3 = r4[3 * G::T + t];
+    m.ma[0] = c0.x; m.ma[1] = c0.y; m.ma[2] = c0.z; m.ma[3] = c0.w;
+    m.ma[4] = c1.x; m.ma[5] = c1.y; m.ma[6] = c1.z; m.ma[7] = c1.w;
+    m.mb[0] = c2.x; m.mb[1] = c2.y; m.mb[2] = c2.z; m.mb[3] = c2.w;
+    m.mb[4] = c3.x; m.mb[5] = c3.y; m.mb[6] = c3.z; m.mb[7] = c3.w;
+    m.m0 = 0.f; m.mn = 0.f;
+    if (t == 0) { m.m0 = m.mb[0]; m.mb[0] = m.ma[0]; m.mn = nyq[0]; }
+}
+// Wave-uniform pointer (SGPR base): lets the loads use "SGPR base + 32-bit lane offset" instead of a 64-bit address
+// pair per access.  Only valid where every lane of the wave holds the same pointer.
+template <class P> GL_DEV P* uniform_ptr(P* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
+// The eight W_N^{k_s} of a lane from ONE table value: k_s = t + B3*s and N/B3 = 16, so W_N^{k_s} = W_N^t * W_16^s (lane 0's
 // permuted slots get their constants).  Costs a few multiplies per frame, saves 14 registers in the fused kernel.
 template <class G> GL_DEV void make_wn(v2f (&w)[8], int t, v2f wt) {
     constexpr double c16[8] = {1.0, kC1, kS2, kS1, 0.0, -kS1, -kS2, -kC1};

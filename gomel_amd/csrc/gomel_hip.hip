@@ -55,11 +55,13 @@ GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
 }
 
 // =============================================================================================== K1: log-mel -> target magnitudes
-// One block per frame.  mag[f][k] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from
+// One block per frame.  mag[f][slot(k)] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from
 // channel 1 at bin N/2-1 (the only survivor of channel 1).  fp64 arithmetic, fp32 result.
+template <int N>
 __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
-                                                    float* __restrict__ mag, float* __restrict__ nyq, int K, int H,
+                                                    float* __restrict__ mag, float* __restrict__ nyq, int K,
                                                     double tune_add, double tune_mul, double inv_n) {
+    constexpr int H = N / 2;
     extern __shared__ double e_sh[];  // [2][K]
     const int64_t f = blockIdx.x;
     const double* m = mel + f * (int64_t)K * 2;
@@ -71,12 +73,20 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
         const BinRow r = undo[i];
         double v0 = (apply_row(r, e_sh) - tune_add) / tune_mul;
-        mag[f * H + i] = (float)(fabs(v0) * inv_n);
+        mag[f * H + mag_slot_index<Geo<N>>(i)] = (float)(fabs(v0) * inv_n);   // lane-slot order, see gl_fft.hpp
         if (i == H - 1) {
             double v1 = (apply_row(r, e_sh + K) - tune_add) / tune_mul;
             nyq[f] = (float)(fabs(v1) * inv_n);
         }
     }
+}
+
+static void launch_mel_to_mag(int N, unsigned frames, size_t shmem, hipStream_t s, const double* mel, const BinRow* undo, float* mag, float* nyq,
+                              int K, double tune_add, double tune_mul) {
+    const double inv_n = 1.0 / (double)N;
+    if (N == 4096) hipLaunchKernelGGL(k_mel_to_mag<4096>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    else if (N == 2048) hipLaunchKernelGGL(k_mel_to_mag<2048>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    else hipLaunchKernelGGL(k_mel_to_mag<1024>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
 }
 
 // =============================================================================================== K3: initial signal
@@ -209,11 +219,17 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     const SegDesc d = segs[seg];
     v2f* my = lds + stream * G::LDS_SLOTS;
 
-    const v2f* xin_p = reinterpret_cast<const v2f*>(x_in + d.s0) + t;      // row r -> xin_p[T*r]
-    v2f* xout_p = reinterpret_cast<v2f*>(x_out + d.s0) + t;
-    const v2f* tprev = reinterpret_cast<const v2f*>(tail_in) + (int64_t)(seg - 1) * TAIL_PAIRS + t;
-    const v2f* town = reinterpret_cast<const v2f*>(tail_in) + (int64_t)seg * TAIL_PAIRS + t;
-    v2f* tout = reinterpret_cast<v2f*>(tail_out) + (int64_t)seg * TAIL_PAIRS + t;
+    // Base pointers.  Streams of T >= 64 lanes are whole waves, so the segment (hence every base) is wave-uniform and
+    // can live in SGPRs; lane offsets are then 32-bit.  (T = 32: two streams share a wave, plain per-lane pointers.)
+    constexpr bool WU = (T >= 64);
+    auto up = [](auto* p) { if constexpr (WU) return uniform_ptr(p); else return p; };
+    const v2f* xin_p = up(reinterpret_cast<const v2f*>(x_in + d.s0));        // row r, lane t -> xin_p[T*r + t]
+    v2f* xout_p = up(reinterpret_cast<v2f*>(x_out + d.s0));
+    const v2f* tprev = up(reinterpret_cast<const v2f*>(tail_in) + (int64_t)(seg - 1) * TAIL_PAIRS);
+    const v2f* town = up(reinterpret_cast<const v2f*>(tail_in) + (int64_t)seg * TAIL_PAIRS);
+    v2f* tout = up(reinterpret_cast<v2f*>(tail_out) + (int64_t)seg * TAIL_PAIRS);
+    const float* mag_p = up(mag + d.frame0 * G::C);
+    const float* nyq_p = up(nyq + d.frame0);
     const int rows_owned = d.G * SH;  // rows >= this belong to the next segment's head
     if constexpr (STREAMS > 1) {  // streams of one WG share the barriers: loop to the longest segment among them
         __shared__ int g_sh[STREAMS];
@@ -227,25 +243,26 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         g_max = d.G;
     }
 
-    v2f xin[16], acc[16];
+    v2f xin[16], acc[KEEP];
     const v2f* wl = win_l + t;  // window pair of row j: wl[T*j]
     const v2f wt = tb.wn[t];
     // Tail terms are loaded unconditionally from a selected pointer (the tables' zero page when no tail applies), so the
     // loads of a frame all go out together instead of one branch + vmcnt(0) each.
-    const v2f* zero_p = reinterpret_cast<const v2f*>(tb.zeros) + t;
+    const v2f* zero_p = up(reinterpret_cast<const v2f*>(tb.zeros));
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const v2f* pp = (d.has_prev && j < KEEP) ? tprev + T * j : zero_p;
         const v2f* pn = (d.has_next && j >= rows_owned) ? town + T * (j - rows_owned) : zero_p;
-        xin[j] = xin_p[T * j] + *pp + *pn;
-        acc[j] = v2f{0.f, 0.f};
+        xin[j] = xin_p[T * j + t] + pp[t] + pn[t];
     }
+#pragma unroll
+    for (int j = 0; j < KEEP; j++) acc[j] = v2f{0.f, 0.f};
 
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
         MagRegs mr;
-        load_mags<G>(mr, t, mag + (d.frame0 + gg) * G::C, nyq + d.frame0 + gg);
+        load_mags<G>(mr, t, mag_p + (int64_t)gg * G::C, nyq_p + gg);
         v2f v[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = xin[j] * wl[T * j];
@@ -258,32 +275,44 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             const int row = (g + 1) * SH + KEEP + jj;
             const v2f* px = more ? xin_p + T * row : zero_p;
             const v2f* pn = (more && d.has_next && row >= rows_owned) ? town + T * (row - rows_owned) : zero_p;
-            xin[KEEP + jj] = *px + *pn;
+            xin[KEEP + jj] = px[t] + pn[t];
         }
         fft_forward<G>(v, my, t, tw, sync);
+#ifndef GOMEL_EXP_NOSPEC
         {
             v2f wn[8];
             make_wn<G>(wn, t, wt);
             spectral_apply<G>(v, t, mr, wn);
         }
+#else
+#pragma unroll
+        for (int s = 0; s < 8; s++) { v[s] *= mr.ma[s]; v[15 - s] *= mr.mb[s]; }
+        v[0].x += mr.m0 + mr.mn + wt.x;
+#endif
         fft_inverse<G>(v, my, t, tw, sync);
         if (active) {
+            // overlap-add in registers: row j of this frame lands on accumulator row j (rows >= KEEP start a new sum);
+            // the first SH rows are finished by this frame and leave, the rest shift down by SH for the next frame.
+            v2f* xo = xout_p + T * (g * SH);
 #pragma unroll
-            for (int j = 0; j < 16; j++) acc[j] += v[j] * wl[T * j];
+            for (int j = 0; j < SH; j++) {
+                const v2f y = v[j] * wl[T * j];
+                xo[T * j + t] = (j < KEEP) ? acc[j] + y : y;
+            }
+            v2f nacc[KEEP];
 #pragma unroll
-            for (int j = 0; j < SH; j++) xout_p[T * (g * SH + j)] = acc[j];   // rows finished by this frame
-            if (g == d.G - 1) {
-                // what is left belongs past the owned range: next segment's head (tail buffer) or the utterance's end
-#pragma unroll
-                for (int j = 0; j < KEEP; j++) {
-                    if (d.has_next) tout[T * j] = acc[SH + j];
-                    else xout_p[T * (rows_owned + j)] = acc[SH + j];
-                }
+            for (int j = 0; j < KEEP; j++) {
+                const v2f y = v[j + SH] * wl[T * (j + SH)];
+                nacc[j] = (j + SH < KEEP) ? acc[j + SH] + y : y;
             }
 #pragma unroll
-            for (int j = 0; j < KEEP; j++) acc[j] = acc[j + SH];
+            for (int j = 0; j < KEEP; j++) acc[j] = nacc[j];
+            if (g == d.G - 1) {
+                // what is left belongs past the owned range: next segment's head (tail buffer) or the utterance's end
+                v2f* dst = d.has_next ? tout : xout_p + T * rows_owned;
 #pragma unroll
-            for (int jj = 0; jj < SH; jj++) acc[KEEP + jj] = v2f{0.f, 0.f};
+                for (int j = 0; j < KEEP; j++) dst[T * j + t] = acc[j];
+            }
         }
     }
 }
@@ -737,8 +766,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_out);
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
-        hipLaunchKernelGGL(k_mel_to_mag, dim3((unsigned)b->total_frames), dim3(256), (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_mag,
-                           b->d_nyq, K, H, c.tune_add, c.tune_mul, 1.0 / (double)N);
+        launch_mel_to_mag(N, (unsigned)b->total_frames, (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
         hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
@@ -1107,7 +1135,7 @@ int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, 
     if (n_pairs == 0) return GOMEL_ERR_EMPTY;
     const int K = h->cfg.num_mels, N = h->cfg.resolut, H = N / 2;
     if (n_pairs % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
-    const size_t F = n_pairs / (size_t)K;
+    const size_t F = n_pairs / (size_t)K;  // (rows come back in lane-slot order and are un-permuted below)
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     double* d_mel = nullptr; float *d_mag = nullptr, *d_nyq = nullptr;
@@ -1116,15 +1144,17 @@ int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, 
         hipMalloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc && hipMemcpyAsync(d_mel, mel, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        hipLaunchKernelGGL(k_mel_to_mag, dim3((unsigned)F), dim3(256), (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, H,
-                           h->cfg.tune_add, h->cfg.tune_mul, 1.0 / (double)N);
+        launch_mel_to_mag(N, (unsigned)F, (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
         std::vector<float> mg(F * H), ny(F);
         if (hipMemcpyAsync(mg.data(), d_mag, F * H * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipMemcpyAsync(ny.data(), d_nyq, F * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
         if (!rc)
             for (size_t f = 0; f < F; f++) {
-                memcpy(mag_out + f * (H + 1), mg.data() + f * H, (size_t)H * 4);
+                for (int k = 0; k < H; k++) {
+                    const int slot = N == 4096 ? mag_slot_index<Geo<4096>>(k) : (N == 2048 ? mag_slot_index<Geo<2048>>(k) : mag_slot_index<Geo<1024>>(k));
+                    mag_out[f * (H + 1) + k] = mg[f * H + slot];
+                }
                 mag_out[f * (H + 1) + H] = ny[f];
             }
     }

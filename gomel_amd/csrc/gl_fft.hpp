@@ -328,12 +328,12 @@ template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restr
     m.m0 = 0.f; m.mn = 0.f;
     if (t == 0) { m.m0 = m.mb[0]; m.mb[0] = m.ma[0]; m.mn = nyq[0]; }
 }
-// Wave-uniform pointer (SGPR base): lets the loads use "SGPR base + 32-bit lane offset" instead of a 64-bit address
-// pair per access.  Only valid where every lane of the wave holds the same pointer.
-template <class P> GL_DEV P* uniform_ptr(P* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (P*)(((unsigned long long)hi << 32) | lo);
+// Wave-uniform 64-bit offset (SGPR pair): `kernel_arg_pointer + uniform offset + 32-bit lane index` lets the loads
+// use "SGPR base + VGPR offset" addressing and keeps the global address space (a pointer rebuilt from integers would
+// degrade to flat_load).  Only valid where every lane of the wave holds the same value.
+GL_DEV long long uniform_i64(long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 // The eight W_N^{k_s} of a lane from ONE table value: k_s = t + B3*s and N/B3 = 16, so W_N^{k_s} = W_N^t * W_16^s (lane 0's
 // permuted slots get their constants).  Costs a few multiplies per frame, saves 14 registers in the fused kernel.

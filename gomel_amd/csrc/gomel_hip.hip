@@ -219,17 +219,19 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     const SegDesc d = segs[seg];
     v2f* my = lds + stream * G::LDS_SLOTS;
 
-    // Base pointers.  Streams of T >= 64 lanes are whole waves, so the segment (hence every base) is wave-uniform and
-    // can live in SGPRs; lane offsets are then 32-bit.  (T = 32: two streams share a wave, plain per-lane pointers.)
+    // Bases = kernel-argument pointer + offset.  Streams of T >= 64 lanes are whole waves, so the segment (hence every
+    // offset) is wave-uniform and is moved to SGPRs; lane offsets are then 32-bit.  (T = 32: two streams share a wave.)
     constexpr bool WU = (T >= 64);
-    auto up = [](auto* p) { if constexpr (WU) return uniform_ptr(p); else return p; };
-    const v2f* xin_p = up(reinterpret_cast<const v2f*>(x_in + d.s0));        // row r, lane t -> xin_p[T*r + t]
-    v2f* xout_p = up(reinterpret_cast<v2f*>(x_out + d.s0));
-    const v2f* tprev = up(reinterpret_cast<const v2f*>(tail_in) + (int64_t)(seg - 1) * TAIL_PAIRS);
-    const v2f* town = up(reinterpret_cast<const v2f*>(tail_in) + (int64_t)seg * TAIL_PAIRS);
-    v2f* tout = up(reinterpret_cast<v2f*>(tail_out) + (int64_t)seg * TAIL_PAIRS);
-    const float* mag_p = up(mag + d.frame0 * G::C);
-    const float* nyq_p = up(nyq + d.frame0);
+    auto uo = [](long long v) { if constexpr (WU) return uniform_i64(v); else return v; };
+    const int seg_prev = d.has_prev ? seg - 1 : seg;                          // clamped: only read with flag f_prev
+    const v2f* xin_p = reinterpret_cast<const v2f*>(x_in) + uo(d.s0 / 2);     // row r, lane t -> xin_p[T*r + t]
+    v2f* xout_p = reinterpret_cast<v2f*>(x_out) + uo(d.s0 / 2);
+    const v2f* tprev = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg_prev * TAIL_PAIRS);
+    const v2f* town = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg * TAIL_PAIRS);
+    v2f* tout = reinterpret_cast<v2f*>(tail_out) + uo((int64_t)seg * TAIL_PAIRS);
+    const float* mag_p = mag + uo(d.frame0 * G::C);
+    const float* nyq_p = nyq + uo(d.frame0);
+    const float f_prev = d.has_prev ? 1.f : 0.f, f_next = d.has_next ? 1.f : 0.f;
     const int rows_owned = d.G * SH;  // rows >= this belong to the next segment's head
     if constexpr (STREAMS > 1) {  // streams of one WG share the barriers: loop to the longest segment among them
         __shared__ int g_sh[STREAMS];
@@ -246,14 +248,15 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     v2f xin[16], acc[KEEP];
     const v2f* wl = win_l + t;  // window pair of row j: wl[T*j]
     const v2f wt = tb.wn[t];
-    // Tail terms are loaded unconditionally from a selected pointer (the tables' zero page when no tail applies), so the
-    // loads of a frame all go out together instead of one branch + vmcnt(0) each.
-    const v2f* zero_p = up(reinterpret_cast<const v2f*>(tb.zeros));
+    // Tail terms are loaded unconditionally (clamped row, times a 0/1 flag) so that all loads of a frame go out together
+    // instead of one branch + vmcnt(0) each; tail buffers are zero-filled at allocation, unused tails stay zero.
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const v2f* pp = (d.has_prev && j < KEEP) ? tprev + T * j : zero_p;
-        const v2f* pn = (d.has_next && j >= rows_owned) ? town + T * (j - rows_owned) : zero_p;
-        xin[j] = xin_p[T * j + t] + pp[t] + pn[t];
+        v2f a = xin_p[T * j + t];
+        if (j < KEEP) a += tprev[T * j + t] * f_prev;
+        const int rn = j >= rows_owned ? j - rows_owned : 0;   // < KEEP because G >= ceil(KEEP/SH) whenever has_next
+        a += town[T * rn + t] * (j >= rows_owned ? f_next : 0.f);
+        xin[j] = a;
     }
 #pragma unroll
     for (int j = 0; j < KEEP; j++) acc[j] = v2f{0.f, 0.f};
@@ -273,9 +276,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) {
             const int row = (g + 1) * SH + KEEP + jj;
-            const v2f* px = more ? xin_p + T * row : zero_p;
-            const v2f* pn = (more && d.has_next && row >= rows_owned) ? town + T * (row - rows_owned) : zero_p;
-            xin[KEEP + jj] = px[t] + pn[t];
+            const int rx = more ? row : 0;                                   // clamped: the value is unused when !more
+            const bool in_next = more && row >= rows_owned;
+            const int rn = in_next ? row - rows_owned : 0;
+            xin[KEEP + jj] = xin_p[T * rx + t] + town[T * rn + t] * (in_next ? f_next : 0.f);
         }
         fft_forward<G>(v, my, t, tw, sync);
 #ifndef GOMEL_EXP_NOSPEC
@@ -309,9 +313,13 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             for (int j = 0; j < KEEP; j++) acc[j] = nacc[j];
             if (g == d.G - 1) {
                 // what is left belongs past the owned range: next segment's head (tail buffer) or the utterance's end
-                v2f* dst = d.has_next ? tout : xout_p + T * rows_owned;
+                if (d.has_next) {
 #pragma unroll
-                for (int j = 0; j < KEEP; j++) dst[T * j + t] = acc[j];
+                    for (int j = 0; j < KEEP; j++) tout[T * j + t] = acc[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KEEP; j++) xout_p[T * (rows_owned + j) + t] = acc[j];
+                }
             }
         }
     }
@@ -1008,6 +1016,8 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
             alloc((void**)&b->d_tail[0], b->segs.size() * (size_t)(N - hop) * 4);
             alloc((void**)&b->d_tail[1], b->segs.size() * (size_t)(N - hop) * 4);
             if (!rc && hipMemcpy(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+            for (int i = 0; i < 2; i++)  // tails of segments without a successor are never written: they must read as zeros
+                if (!rc && hipMemset(b->d_tail[i], 0, b->segs.size() * (size_t)(N - hop) * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
         }
     }
     for (auto& e : b->ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = GOMEL_ERR_HIP;

@@ -84,9 +84,150 @@ constexpr double kS2 = 0.70710678118654752440;  // sqrt(1/2)
 constexpr double kC1 = 0.92387953251128675613;  // cos(pi/8)
 constexpr double kS1 = 0.38268343236508977173;  // sin(pi/8)
 
-template <bool INV, class V> GL_DEV void dft4(V& a0, V& a1, V& a2, V& a3) {
+template <bool INV, class V> GL_DEV void dft4_c(V& a0, V& a1, V& a2, V& a3) {
     V s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = mul_mi<INV>(a1 - a3);
     a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+}
+
+// ---------------------------------------------------------------------------------------------- fp32 packed-math asm forms
+// hipcc folds lane broadcasts into VOP3P op_sel but not lane SWAPS or single-lane negations: every multiply by +-i and
+// every complex multiply costs an extra v_xor + v_mov.  These blocks spell the packed instructions with their modifiers.
+// Hazard rule honoured by construction (CDNA3/4 ISA, manually inserted wait states): a VALU that uses OPSEL needs one
+// wait state before a consumer of its result -- inside a block no instruction consumes the result of the one right
+// before it (or an s_nop sits between), and hipcc pads the block's outputs itself after the statement.  Every block
+// opens with its non-OPSEL reads or an s_nop, because hipcc does not check a block's inputs against the instruction
+// it places in front of it.  -DGOMEL_NO_PKASM builds the plain C++ forms (bit-identical results; used as a cross-check).
+#ifndef GOMEL_NO_PKASM
+#define GL_PKASM 1
+#else
+#define GL_PKASM 0
+#endif
+#ifndef GL_PKASM_DFT4
+#define GL_PKASM_DFT4 GL_PKASM
+#endif
+#ifndef GL_PKASM_TW
+#define GL_PKASM_TW GL_PKASM
+#endif
+#ifndef GL_PKASM_CONST
+#define GL_PKASM_CONST GL_PKASM
+#endif
+
+// (a0, a1) <- (a0 * w0, a1 * w1), or * conj(w) when CONJ.  w may be VGPR pairs or (uniform constants) SGPR pairs.
+template <bool CONJ> GL_DEV void cmul2_asm(v2f& a0, v2f w0, v2f& a1, v2f w1) {
+    v2f t0, t1;
+    if (!CONJ)
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+            "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+            : "=&v"(t0), "=&v"(t1), "+v"(a0), "+v"(a1) : "v"(w0), "v"(w1));
+    else
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+            "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(t0), "=&v"(t1), "+v"(a0), "+v"(a1) : "v"(w0), "v"(w1));
+}
+template <bool CONJ> GL_DEV void cmul1_asm(v2f& a0, v2f w0) {
+    v2f t0;
+    if (!CONJ)
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+            : "=&v"(t0), "+v"(a0) : "v"(w0));
+    else
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(t0), "+v"(a0) : "v"(w0));
+}
+// same with the multiplier a uniform constant held in an SGPR pair
+template <bool CONJ> GL_DEV void cmul2_sconst_asm(v2f& a0, v2f k0, v2f& a1, v2f k1) {
+    v2f t0, t1;
+    if (!CONJ)
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+            "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+            : "=&v"(t0), "=&v"(t1), "+v"(a0), "+v"(a1) : "s"(k0), "s"(k1));
+    else
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+            "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(t0), "=&v"(t1), "+v"(a0), "+v"(a1) : "s"(k0), "s"(k1));
+}
+template <bool CONJ> GL_DEV void cmul1_sconst_asm(v2f& a0, v2f k0) {
+    v2f t0;
+    if (!CONJ)
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+            : "=&v"(t0), "+v"(a0) : "s"(k0));
+    else
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+            "s_nop 0\n\t"
+            "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(t0), "+v"(a0) : "s"(k0));
+}
+// radix-4 butterfly, 8 packed adds: the multiply of (a1 - a3) by -+i is folded into the last two adds' op_sel/neg.
+template <bool INV> GL_DEV void dft4_asm(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+    v2f tA, tB;
+    if (!INV)
+        asm("v_pk_add_f32 %0, %2, %4\n\t"                                   // tA = a0 + a2
+            "v_pk_add_f32 %2, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"         // a0 = a0 - a2
+            "v_pk_add_f32 %1, %3, %5\n\t"                                   // tB = a1 + a3
+            "v_pk_add_f32 %3, %3, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"         // a1 = a1 - a3
+            "v_pk_add_f32 %4, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"         // a2 = tA - tB            (X2)
+            "v_pk_add_f32 %0, %0, %1\n\t"                                   // tA = tA + tB            (X0)
+            "v_pk_add_f32 %5, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   // a3 = d02 + i d   (X3)
+            "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"       // a1 = d02 - i d   (X1)
+            : "=&v"(tA), "=&v"(tB), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    else
+        asm("v_pk_add_f32 %0, %2, %4\n\t"
+            "v_pk_add_f32 %2, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %3, %5\n\t"
+            "v_pk_add_f32 %3, %3, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %4, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %0, %0, %1\n\t"
+            "v_pk_add_f32 %5, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"   // a3 = d02 - i d   (X3, inverse)
+            "v_pk_add_f32 %3, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"       // a1 = d02 + i d   (X1, inverse)
+            : "=&v"(tA), "=&v"(tB), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    a0 = tA;
+}
+
+template <bool INV, class V> GL_DEV void dft4(V& a0, V& a1, V& a2, V& a3) {
+    if constexpr (GL_PKASM_DFT4 && __is_same(V, v2f)) dft4_asm<INV>(a0, a1, a2, a3); else dft4_c<INV>(a0, a1, a2, a3);
+}
+// (a0, a1) *= W^{+-1}-style constant twiddles (c - i s) forward / (c + i s) inverse
+template <bool INV, class V> GL_DEV void twc2(V& a0, double c0, double s0, V& a1, double c1, double s1) {
+    if constexpr (GL_PKASM_CONST && __is_same(V, v2f)) {
+        // a*(c - i s) = a*conj(c + i s): CONJ form forward, plain form inverse, constant (c, s) in an SGPR pair
+        cmul2_sconst_asm<!INV>(a0, v2f{(float)c0, (float)s0}, a1, v2f{(float)c1, (float)s1});
+    } else { a0 = twc<INV>(a0, c0, s0); a1 = twc<INV>(a1, c1, s1); }
+}
+template <bool INV, class V> GL_DEV void twc1(V& a0, double c0, double s0) {
+    if constexpr (GL_PKASM_CONST && __is_same(V, v2f)) cmul1_sconst_asm<!INV>(a0, v2f{(float)c0, (float)s0});
+    else a0 = twc<INV>(a0, c0, s0);
+}
+// v[i] *= w[i] (or conj) for i in [1, n), in interleaved pairs
+template <bool CONJ, int STRIDE, int CNT, class V> GL_DEV void apply_tw(V* v, const V* w) {
+    if constexpr (GL_PKASM_TW && __is_same(V, v2f)) {
+#pragma unroll
+        for (int q = 1; q + 1 < CNT; q += 2) cmul2_asm<CONJ>(v[q * STRIDE], w[q * STRIDE], v[(q + 1) * STRIDE], w[(q + 1) * STRIDE]);
+        if constexpr ((CNT - 1) % 2 == 1) cmul1_asm<CONJ>(v[(CNT - 1) * STRIDE], w[(CNT - 1) * STRIDE]);
+    } else {
+#pragma unroll
+        for (int q = 1; q < CNT; q++) v[q * STRIDE] = CONJ ? cmulc(v[q * STRIDE], w[q * STRIDE]) : cmul(v[q * STRIDE], w[q * STRIDE]);
+    }
 }
 
 // In-place DFT of R registers at stride S in v[]; output q lands in v[q*S] (natural order).
@@ -94,9 +235,8 @@ template <bool INV, int S, class V> GL_DEV void dft8(V* v) {
     V u0[4], u1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { u0[j] = v[j * S] + v[(j + 4) * S]; u1[j] = v[j * S] - v[(j + 4) * S]; }
-    u1[1] = twc<INV>(u1[1], kS2, kS2);
+    twc2<INV>(u1[1], kS2, kS2, u1[3], -kS2, kS2);
     u1[2] = mul_mi<INV>(u1[2]);
-    u1[3] = twc<INV>(u1[3], -kS2, kS2);
     dft4<INV>(u0[0], u0[1], u0[2], u0[3]);
     dft4<INV>(u1[0], u1[1], u1[2], u1[3]);
 #pragma unroll
@@ -111,15 +251,11 @@ template <bool INV, int S, class V> GL_DEV void dft16(V* v) {
         dft4<INV>(u[j][0], u[j][1], u[j][2], u[j][3]);
     }
     // u[j][p] *= W16^{j p}
-    u[1][1] = twc<INV>(u[1][1], kC1, kS1);
-    u[1][2] = twc<INV>(u[1][2], kS2, kS2);
-    u[1][3] = twc<INV>(u[1][3], kS1, kC1);
-    u[2][1] = twc<INV>(u[2][1], kS2, kS2);
+    twc2<INV>(u[1][1], kC1, kS1, u[1][2], kS2, kS2);
+    twc2<INV>(u[1][3], kS1, kC1, u[2][1], kS2, kS2);
     u[2][2] = mul_mi<INV>(u[2][2]);
-    u[2][3] = twc<INV>(u[2][3], -kS2, kS2);
-    u[3][1] = twc<INV>(u[3][1], kS1, kC1);
-    u[3][2] = twc<INV>(u[3][2], -kS2, kS2);
-    u[3][3] = twc<INV>(u[3][3], -kC1, -kS1);
+    twc2<INV>(u[2][3], -kS2, kS2, u[3][1], kS1, kC1);
+    twc2<INV>(u[3][2], -kS2, kS2, u[3][3], -kC1, -kS1);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         dft4<INV>(u[0][p], u[1][p], u[2][p], u[3][p]);
@@ -147,9 +283,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<false, G::R1, G::NB1>(&v[u]);
 #pragma unroll
-    for (int u = 0; u < G::NB1; u++)
-#pragma unroll
-        for (int q = 1; q < G::R1; q++) v[u + G::NB1 * q] = cmul(v[u + G::NB1 * q], w1[u + G::NB1 * q]);
+    for (int u = 0; u < G::NB1; u++) apply_tw<false, G::NB1, G::R1>(&v[u], &w1[u]);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
@@ -175,8 +309,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         dftR<false, G::R2, 1>(&v[u * G::R2]);
-#pragma unroll
-        for (int q = 1; q < G::R2; q++) v[u * G::R2 + q] = cmul(v[u * G::R2 + q], w2[u * G::R2 + q]);
+        apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
     }
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
@@ -207,12 +340,13 @@ template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* 
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
+        V w2[16];
 #pragma unroll
         for (int q = 0; q < G::R2; q++) {
-            V val = lds[t2 * G::SB + q1 + G::R1 * q];
-            if (q) val = cmulc(val, tw.tw2[q * 8 + t2]);
-            v[u * G::R2 + q] = val;
+            v[u * G::R2 + q] = lds[t2 * G::SB + q1 + G::R1 * q];
+            if (q) w2[q] = tw.tw2[q * 8 + t2];
         }
+        apply_tw<true, 1, G::R2>(&v[u * G::R2], w2);
     }
     sync();
 #pragma unroll
@@ -226,12 +360,13 @@ template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* 
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
+        V w1[16];
 #pragma unroll
         for (int q = 0; q < G::R1; q++) {
-            V val = lds[q * G::SA + t1];
-            if (q) val = cmulc(val, tw.tw1[q * G::C1 + t1]);
-            v[u + G::NB1 * q] = val;
+            v[u + G::NB1 * q] = lds[q * G::SA + t1];
+            if (q) w1[G::NB1 * q] = tw.tw1[q * G::C1 + t1];
         }
+        apply_tw<true, G::NB1, G::R1>(&v[u], w1);
     }
     sync();
 #pragma unroll

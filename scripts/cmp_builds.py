@@ -1,0 +1,40 @@
+"""Bitwise comparison of two builds of the library on the same inputs (hazard check for the inline-asm forms)."""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import importlib
+
+def run(libpath, geom, U, F, I, reps):
+    from gomel_amd import _lib
+    _lib._lib = None
+    _lib.LIB_PATH = os.path.abspath(libpath)
+    import gomel_amd
+    G = {"T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096), "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),
+         "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048)}[geom]
+    m = gomel_amd.NewMel()
+    for k, v in dict(G, GriffinLimIterations=I).items():
+        setattr(m, k, v)
+    e = m.engine()
+    mels = [np.random.default_rng(u).uniform(np.log(1e-5), np.log(50.0), size=(F * m.NumMels, 2)) for u in range(U)]
+    b = gomel_amd.Batch(e, [F * m.NumMels] * U)
+    b.upload(mels, None, list(range(U)))
+    outs = []
+    for _ in range(reps):
+        b.run()
+        outs.append(np.concatenate(b.download()))
+    b.close(); e.close()
+    return outs
+
+if __name__ == "__main__":
+    a_lib, b_lib = sys.argv[1], sys.argv[2]
+    ok = True
+    for geom in ("T", "D", "S"):
+        A = run(a_lib, geom, 64, 100, 10, 3)
+        B = run(b_lib, geom, 64, 100, 10, 1)
+        same_runs = all(np.array_equal(A[0], x) for x in A[1:])
+        same_builds = np.array_equal(A[0], B[0])
+        d = float(np.sqrt(np.mean((A[0] - B[0]) ** 2)))
+        print(geom, "run-to-run identical:", same_runs, "| builds identical:", same_builds, "rms diff %.3e" % d, "finite", bool(np.isfinite(A[0]).all()))
+        ok &= same_runs and (same_builds or d < 1e-6)
+    sys.exit(0 if ok else 1)

@@ -282,6 +282,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
         for (int q = 1; q < G::R1; q++) w1[u + G::NB1 * q] = tw.tw1[q * G::C1 + t + G::T * u];
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<false, G::R1, G::NB1>(&v[u]);
+    __builtin_amdgcn_sched_barrier(0);   // keep the twiddle reads above the butterfly: they land while it computes
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) apply_tw<false, G::NB1, G::R1>(&v[u], &w1[u]);
 #pragma unroll
@@ -307,10 +308,10 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
         for (int q = 1; q < G::R2; q++) w2[u * G::R2 + q] = tw.tw2[q * 8 + t2];
     }
 #pragma unroll
-    for (int u = 0; u < G::NB2; u++) {
-        dftR<false, G::R2, 1>(&v[u * G::R2]);
-        apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
-    }
+    for (int u = 0; u < G::NB2; u++) dftR<false, G::R2, 1>(&v[u * G::R2]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < G::NB2; u++) apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;

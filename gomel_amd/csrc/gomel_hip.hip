@@ -216,8 +216,14 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     int seg = blockIdx.x * STREAMS + stream;
     const bool live = seg < n_segs;
     if (!live) seg = n_segs - 1;
-    const SegDesc d = segs[seg];
+    SegDesc d = segs[seg];
     v2f* my = lds + stream * G::LDS_SLOTS;
+    if constexpr (T >= 64) {  // whole-wave streams: the descriptor is wave-uniform -> keep it (and all row logic) in SGPRs
+        d.G = __builtin_amdgcn_readfirstlane(d.G);
+        d.has_prev = __builtin_amdgcn_readfirstlane(d.has_prev);
+        d.has_next = __builtin_amdgcn_readfirstlane(d.has_next);
+        seg = __builtin_amdgcn_readfirstlane(seg);
+    }
 
     // Bases = kernel-argument pointer + offset.  Streams of T >= 64 lanes are whole waves, so the segment (hence every
     // offset) is wave-uniform and is moved to SGPRs; lane offsets are then 32-bit.  (T = 32: two streams share a wave.)
@@ -267,8 +273,12 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         MagRegs mr;
         load_mags<G>(mr, t, mag_p + (int64_t)gg * G::C, nyq_p + gg);
         v2f v[16];
+        // all 16 window reads go out back to back (one LDS round trip, not sixteen), then the multiplies
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = xin[j] * wl[T * j];
+        for (int j = 0; j < 16; j++) v[j] = wl[T * j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] *= xin[j];
         // slide the input window now: the next frame's SH new rows (hop samples) load behind the two FFTs
 #pragma unroll
         for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];

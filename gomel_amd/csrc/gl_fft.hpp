@@ -407,15 +407,22 @@ template <class G> GL_DEV void lane0_unpermute(v2f (&v)[16], bool is0, v2f dc) {
 // unit phasor of X with the reference's zero rule: cmplx.Phase(0) = 0 -> Rect(M, 0) = M (mel/mel.go:100-101)
 GL_DEV v2f unit_phase(v2f x) {
     float p = x.x * x.x + x.y * x.y;
-    float r = __builtin_amdgcn_rsqf(p);
-    // one Newton step: v_rsq_f32 is ~1 ulp, keep the phasor at fp32 accuracy
-    r = r * (1.5f - 0.5f * p * r * r);
+    float r = __builtin_amdgcn_rsqf(p);   // v_rsq_f32: 1 ulp
     return p > 0.f ? v2f{x.x * r, x.y * r} : v2f{1.f, 0.f};
+}
+// the same for inputs whose squared modulus under/overflows fp32 (rare path)
+GL_DEV v2f unit_phase_safe(v2f x) {
+    const float big = fmaxf(fabsf(x.x), fabsf(x.y));
+    if (!(big > 0.f)) return v2f{1.f, 0.f};
+    const float sc = 1.0f / big;            // bring the larger component to 1: no under/overflow in the square
+    const v2f y = v2f{x.x * sc, x.y * sc};
+    const float r = __builtin_amdgcn_rsqf(y.x * y.x + y.y * y.y);
+    return v2f{y.x * r, y.y * r};
 }
 
 // Real-FFT split -> X[k], X[C-k]; Y = Ms * X/|X|; merge -> Z'[k], Z'[C-k].  ma/mb are the (1/N-scaled) target
 // magnitudes of bins k and C-k, w = W_N^k.  a = Z[k], b = Z[C-k] on entry; Z'[k], Z'[C-k] on exit.
-GL_DEV void clamp_pair(v2f& a, v2f& b, v2f w, float ma, float mb) {
+GL_DEV void clamp_pair_c(v2f& a, v2f& b, v2f w, float ma, float mb) {
     v2f bc = v2f{b.x, -b.y};
     v2f p = a + bc;                      // 2 E_k
     v2f d = a - bc;                      // 2 i O_k
@@ -430,6 +437,61 @@ GL_DEV void clamp_pair(v2f& a, v2f& b, v2f w, float ma, float mb) {
     a = e + io;                          // E' + i O'
     v2f t = e - io;                      // E' - i O'
     b = v2f{t.x, -t.y};                  // conj(E' - i O')
+}
+
+// Two bin pairs at once in packed math with op_sel/neg modifiers (same arithmetic as clamp_pair_c, 28 VALU per pair
+// instead of ~60).  The two pairs are interleaved so that no instruction consumes the result of the one before it.
+GL_DEV void clamp_pairs2(v2f& a0, v2f& b0, v2f w0, float ma0, float mb0, v2f& a1, v2f& b1, v2f w1, float ma1, float mb1) {
+#if GL_PKASM
+    {   // a <- 2 X[k] = p + q, b <- 2 conj(X[C-k]) = p - q, with p = a + conj(b), q = w * (-i)(a - conj(b))
+        v2f p0, q0, t0, p1, q1, t1;
+        asm("s_nop 0\n\t"
+            "v_pk_add_f32 %0, %6, %7 neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %3, %8, %9 neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %1, %6, %7 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %4, %8, %9 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %2, %1, %10 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %5, %4, %11 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %1, %1, %10, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+            "v_pk_fma_f32 %4, %4, %11, %5 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+            "v_pk_add_f32 %6, %0, %1\n\t"
+            "v_pk_add_f32 %8, %3, %4\n\t"
+            "v_pk_add_f32 %7, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_pk_add_f32 %9, %3, %4 neg_lo:[0,1] neg_hi:[0,1]"
+            : "=&v"(p0), "=&v"(q0), "=&v"(t0), "=&v"(p1), "=&v"(q1), "=&v"(t1), "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1)
+            : "v"(w0), "v"(w1));
+    }
+    // phasors: |x|^2, v_rsq, scale by the target magnitude
+    const float pa0 = a0.x * a0.x + a0.y * a0.y, pb0 = b0.x * b0.x + b0.y * b0.y;
+    const float pa1 = a1.x * a1.x + a1.y * a1.y, pb1 = b1.x * b1.x + b1.y * b1.y;
+    v2f u0 = a0 * (__builtin_amdgcn_rsqf(pa0) * ma0), v0 = b0 * (__builtin_amdgcn_rsqf(pb0) * mb0);
+    v2f u1 = a1 * (__builtin_amdgcn_rsqf(pa1) * ma1), v1 = b1 * (__builtin_amdgcn_rsqf(pb1) * mb1);
+    // rare, wave-uniform: a modulus that is exactly zero (reference: phase 0, Y = M) or outside rsq's safe range
+    const float plo = fminf(fminf(pa0, pb0), fminf(pa1, pb1)), phi = fmaxf(fmaxf(pa0, pb0), fmaxf(pa1, pb1));
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(plo > 1e-30f) || !(phi < 1e30f)) != 0, 0)) {
+        u0 = unit_phase_safe(a0) * ma0; v0 = unit_phase_safe(b0) * mb0;
+        u1 = unit_phase_safe(a1) * ma1; v1 = unit_phase_safe(b1) * mb1;
+    }
+    v2f e0 = u0 + v0, f0 = u0 - v0, e1 = u1 + v1, f1 = u1 - v1;
+    {   // o = conj(w) f;  a <- e + i o;  b <- conj(e - i o)
+        v2f t0, t1;
+        asm("s_nop 0\n\t"
+            "v_pk_mul_f32 %0, %3, %6 op_sel_hi:[1,0]\n\t"
+            "v_pk_mul_f32 %1, %5, %7 op_sel_hi:[1,0]\n\t"
+            "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+            "v_pk_fma_f32 %1, %5, %7, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
+            "v_pk_add_f32 %3, %2, %0 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %5, %4, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 %2, %2, %0 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+            "v_pk_add_f32 %4, %4, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
+            : "=&v"(t0), "=&v"(t1), "+v"(e0), "+v"(f0), "+v"(e1), "+v"(f1)
+            : "v"(w0), "v"(w1));
+    }
+    a0 = f0; b0 = e0; a1 = f1; b1 = e1;   // block 2 leaves Z'[k] in f, Z'[C-k] in e
+#else
+    clamp_pair_c(a0, b0, w0, ma0, mb0);
+    clamp_pair_c(a1, b1, w1, ma1, mb1);
+#endif
 }
 
 // Target magnitudes a lane needs for one frame.  A frame's row of N/2 magnitudes is stored in LANE-SLOT order
@@ -498,7 +560,7 @@ template <class G> GL_DEV void spectral_apply(v2f (&v)[16], int t, const MagRegs
     v2f dc = v[0];
     lane0_permute<G>(v, is0);
 #pragma unroll
-    for (int s = 0; s < 8; s++) clamp_pair(v[s], v[15 - s], w[s], m.ma[s], m.mb[s]);
+    for (int s = 0; s < 8; s += 2) clamp_pairs2(v[s], v[15 - s], w[s], m.ma[s], m.mb[s], v[s + 1], v[14 - s], w[s + 1], m.ma[s + 1], m.mb[s + 1]);
     if (is0) {
         // DC and Nyquist: X[0] = Re+Im, X[N/2] = Re-Im (real); Y = +-M; Z'[0] = (Y0+Yn) + i (Y0-Yn)
         float x0 = dc.x + dc.y, xn = dc.x - dc.y;

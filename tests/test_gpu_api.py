@@ -156,7 +156,10 @@ def test_full_size_config3_properties(oracle):
     o_same = m.engine().from_mel_batch([mels[u] for u in sub], None, [seeds[u] for u in sub])
     for u, a, s in zip(sub, o_half, o_same):
         assert np.array_equal(a, 2.0 * s)                                               # exact: scaling by 2 commutes with rounding
-        assert rms(s - out1[u]) < 2e-5                                                  # other batch, other segmentation: rounding only
+        # other batch shape -> other segmentation -> other fp32 summation order.  Griffin-Lim keeps only the PHASE of each
+        # bin, which is ill-conditioned where |X[k]| sinks to the FFT's rounding floor; on these iid-random magnitudes a few
+        # such bins per utterance flip differently between two roundings (isolated spikes, typical RMS 1e-6, tail ~5e-5).
+        assert rms(s - out1[u]) < RMS_TOL
     cfg = oracle.MelConfig(**fields)
     for u in (3, 200):
         want = oracle.from_mel(cfg, mels[u].copy(), oracle.x0_splitmix(seeds[u], L))

@@ -178,3 +178,46 @@ def test_hops_fused_and_generic(oracle, hop):
     want = oracle.from_mel(cfg, mel.copy(), x0)
     got = m.FromMel(mel.copy(), x0=x0)
     assert rms(got - want) < RMS_TOL
+
+
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("geom", ["T", "S"])
+def test_zero_signal_takes_the_phase_zero_rule(oracle, geom, path):
+    """x0 = 0 makes every re-STFT bin exactly zero: cmplx.Phase(0) = 0, so the reference imposes Y = M (mel.go:100-101).
+    In the kernels this is the rare wave-uniform branch of the spectral step."""
+    # (one iteration: after it the signal is a train of symmetric pulses with almost purely real spectra, whose phases sit on
+    # the 0/pi knife-edge -- fp32 and fp64 then part ways by ~1e-3 relative, which says nothing about the rule under test)
+    m = make_mel(geom, 1, path)
+    cfg = ocfg(oracle, geom, 1)
+    mel = oracle.random_logmel(7, cfg.NumMels, seed=2)
+    L = oracle.out_len(cfg, len(mel))
+    x0 = np.zeros(L)
+    want = oracle.from_mel(cfg, mel.copy(), x0)
+    got = m.FromMel(mel.copy(), x0=x0)
+    assert rms(want) > 1e-3 and rms(got - want) < 1e-6 * rms(want) + 1e-7
+    # one silent stretch inside an otherwise random signal
+    m = make_mel(geom, 2, path)
+    cfg = ocfg(oracle, geom, 2)
+    mel = oracle.random_logmel(9, cfg.NumMels, seed=4)
+    L = oracle.out_len(cfg, len(mel))
+    x0 = oracle.x0_splitmix(5, L)
+    x0[2 * cfg.Window: 2 * cfg.Window + cfg.Resolut] = 0.0          # frame 2 sees only zeros
+    assert rms(m.FromMel(mel.copy(), x0=x0) - oracle.from_mel(cfg, mel.copy(), x0)) < RMS_TOL
+
+
+def test_extreme_magnitudes_and_negative_tune(oracle):
+    """Huge and tiny target magnitudes (moduli outside v_rsq's comfortable range) and TuneMul < 0 (targets go through
+    cmplx.Abs, mel.go:99)."""
+    for scale, tol in ((30.0, 1e-4), (-30.0, 1e-4)):
+        m = make_mel("S", 2)
+        cfg = ocfg(oracle, "S", 2)
+        mel = oracle.random_logmel(6, 80, seed=8) + scale           # magnitudes * e^+-30
+        x0 = oracle.x0_splitmix(3, oracle.out_len(cfg, len(mel))) * (1e-12 if scale < 0 else 1e12)
+        want = oracle.from_mel(cfg, mel.copy(), x0)
+        got = m.FromMel(mel.copy(), x0=x0)
+        assert np.all(np.isfinite(got)) and rms(got - want) < tol * rms(want)
+    m = make_mel("T", 3, TuneMul=-2.0, TuneAdd=0.5)
+    cfg = ocfg(oracle, "T", 3, TuneMul=-2.0, TuneAdd=0.5)
+    mel = oracle.random_logmel(5, 192, seed=9)
+    x0 = oracle.x0_splitmix(4, oracle.out_len(cfg, len(mel)))
+    assert rms(m.FromMel(mel.copy(), x0=x0) - oracle.from_mel(cfg, mel.copy(), x0)) < RMS_TOL

@@ -109,14 +109,15 @@ def cpu_baseline(fields, frames, max_seconds_hint=30.0):
     co.from_mel(cfg, small, go.x0_splitmix(0, go.out_len(cfg, len(small))))
     per_frame = (time.perf_counter() - t) / 4.0
     f_s = int(max(8, min(frames, (max_seconds_hint / 2.0) / max(per_frame, 1e-6))))
-    mels = [go.random_logmel(f_s, cfg.NumMels, seed=u) for u in range(cores)]
+    reps = 2 if f_s * per_frame < 8.0 else 1          # aim at 10-30 s of wall time on the sample
+    mels = [go.random_logmel(f_s, cfg.NumMels, seed=u) for u in range(cores * reps)]
     x0s = [go.x0_splitmix(1000 + u, go.out_len(cfg, len(m))) for u, m in enumerate(mels)]
     t = time.perf_counter()
     _, used = co.from_mel_batch(cfg, mels, x0s, threads=cores)
     dt = time.perf_counter() - t
-    return {"value": cores * f_s / dt, "unit": "frames/s", "cores": int(used), "kind": "port",
-            "sample": "%d utterances x %d frames x %d iters (one per thread), C restatement of mel.go:76-152, %.1f s" % (
-                cores, f_s, cfg.GriffinLimIterations, dt),
+    return {"value": len(mels) * f_s / dt, "unit": "frames/s", "cores": int(used), "kind": "port",
+            "sample": "%d utterances x %d frames x %d iters on %d threads, C restatement of mel.go:76-152, %.1f s" % (
+                len(mels), f_s, cfg.GriffinLimIterations, cores, dt),
             "single_thread_frames_per_s": 1.0 / per_frame}
 
 

@@ -1,0 +1,101 @@
+"""CPU test: the gfx950 ISA of the HIP library honours the "VALU that uses OPSEL -> 1 wait state before a consumer" rule
+(CDNA ISA, manually inserted wait states) everywhere, including inside and between the hand-written packed-math asm blocks of
+gl_fft.hpp, where hipcc's own hazard recogniser does not look.  Also: no scratch (spill) traffic in the fused kernel's loop."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gomel_amd", "csrc", "gomel_hip.hip")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "gomel.s")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", "-o", out, SRC],
+                   check=True, stderr=subprocess.DEVNULL)
+    return [l.rstrip() for l in open(out)]
+
+
+def _regs(text):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def _instructions(lines):
+    for l in lines:
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":") or t.startswith("//"):
+            continue
+        yield t.split(";")[0].strip()
+
+
+def test_asm_blocks_never_consume_an_opsel_result_in_the_next_instruction(isa):
+    """Conservative form of the rule, applied to the hand-written blocks only (hipcc pads its own code, and pads a block's
+    outputs before ITS next instruction, but knows nothing about the inside of a block or about a block that directly
+    follows another): within a block, and from the last instruction of a block to the first of a directly following one, no
+    instruction may read the destination of an immediately preceding packed op that carries op_sel."""
+    blocks, cur, prev_end = [], None, None
+    seq = []                                    # (kind, text): kind in {"asm", "code"}
+    for l in isa:
+        t = l.strip()
+        if "ASMSTART" in t:
+            cur = []
+            continue
+        if "ASMEND" in t:
+            seq.append(("asm", cur))
+            cur = None
+            continue
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        if cur is not None:
+            cur.append(t)
+        else:
+            seq.append(("code", t))
+    n_blocks = n_pairs = 0
+    bad = []
+
+    def hazard(a, b):
+        if not (a.startswith("v_pk_") and "op_sel" in a) or not b.startswith("v_"):
+            return False
+        return bool(_regs(a.split(",")[0]) & _regs(",".join(b.split(None, 1)[1].split(",")[1:])))
+
+    for i, (kind, item) in enumerate(seq):
+        if kind != "asm" or not item:
+            continue
+        n_blocks += 1
+        for a, b in zip(item, item[1:]):
+            n_pairs += 1
+            if hazard(a, b):
+                bad.append((a, b))
+        if i + 1 < len(seq) and seq[i + 1][0] == "asm" and seq[i + 1][1]:
+            if hazard(item[-1], seq[i + 1][1][0]):
+                bad.append((item[-1], seq[i + 1][1][0]))
+    assert n_blocks > 300 and n_pairs > 2000      # the packed forms are in use in every instantiation
+    assert not bad, bad[:5]
+
+
+def test_fused_kernel_loop_has_no_scratch_traffic_for_the_bench_geometry(isa):
+    name = "_Z10k_gl_fusedILi4096ELi5EE"
+    start = next(i for i, l in enumerate(isa) if l.startswith(name) and ":" in l)
+    end = next(i for i in range(start, len(isa)) if "s_endpgm" in isa[i])
+    body = isa[start:end]
+    mags = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
+    assert len(mags) >= 4                          # the four 16-byte magnitude loads of the lane-slot layout
+    stores = [i for i, l in enumerate(body) if "global_store_dwordx2" in l]
+    loop = body[mags[-4] - 10: stores[4] + 1]      # top of a frame ... the frame's five finished rows stored
+    assert len(loop) > 1000
+    assert not any("scratch_" in l for l in loop), "spill in the steady-state loop of k_gl_fused<4096,5>"
+    assert not any(l.strip().startswith("flat_") for l in body), "a global access degraded to flat_"

@@ -102,6 +102,11 @@ template <bool INV, class V> GL_DEV void dft4_c(V& a0, V& a1, V& a2, V& a3) {
 #else
 #define GL_PKASM 0
 #endif
+#ifdef GOMEL_EXP_NOLEADNOP
+#define GL_LEAD_NOP ""
+#else
+#define GL_LEAD_NOP "s_nop 0\n\t"
+#endif
 #ifndef GL_PKASM_DFT4
 #define GL_PKASM_DFT4 GL_PKASM
 #endif
@@ -116,14 +121,14 @@ template <bool INV, class V> GL_DEV void dft4_c(V& a0, V& a1, V& a2, V& a3) {
 template <bool CONJ> GL_DEV void cmul2_asm(v2f& a0, v2f w0, v2f& a1, v2f w1) {
     v2f t0, t1;
     if (!CONJ)
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
             "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
             "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
             "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
             : "=&v"(t0), "=&v"(t1), "+v"(a0), "+v"(a1) : "v"(w0), "v"(w1));
     else
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
             "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
             "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
@@ -133,13 +138,13 @@ template <bool CONJ> GL_DEV void cmul2_asm(v2f& a0, v2f w0, v2f& a1, v2f w1) {
 template <bool CONJ> GL_DEV void cmul1_asm(v2f& a0, v2f w0) {
     v2f t0;
     if (!CONJ)
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
             "s_nop 0\n\t"
             "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
             : "=&v"(t0), "+v"(a0) : "v"(w0));
     else
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
             "s_nop 0\n\t"
             "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
@@ -149,14 +154,14 @@ template <bool CONJ> GL_DEV void cmul1_asm(v2f& a0, v2f w0) {
 template <bool CONJ> GL_DEV void cmul2_sconst_asm(v2f& a0, v2f k0, v2f& a1, v2f k1) {
     v2f t0, t1;
     if (!CONJ)
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
             "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
             "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
             "v_pk_fma_f32 %3, %3, %5, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
             : "=&v"(t0), "=&v"(t1), "+v"(a0), "+v"(a1) : "s"(k0), "s"(k1));
     else
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %2, %4 op_sel_hi:[1,0]\n\t"
             "v_pk_mul_f32 %1, %3, %5 op_sel_hi:[1,0]\n\t"
             "v_pk_fma_f32 %2, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"
@@ -166,13 +171,13 @@ template <bool CONJ> GL_DEV void cmul2_sconst_asm(v2f& a0, v2f k0, v2f& a1, v2f 
 template <bool CONJ> GL_DEV void cmul1_sconst_asm(v2f& a0, v2f k0) {
     v2f t0;
     if (!CONJ)
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
             "s_nop 0\n\t"
             "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
             : "=&v"(t0), "+v"(a0) : "s"(k0));
     else
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
             "s_nop 0\n\t"
             "v_pk_fma_f32 %1, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
@@ -445,7 +450,7 @@ GL_DEV void clamp_pairs2(v2f& a0, v2f& b0, v2f w0, float ma0, float mb0, v2f& a1
 #if GL_PKASM
     {   // a <- 2 X[k] = p + q, b <- 2 conj(X[C-k]) = p - q, with p = a + conj(b), q = w * (-i)(a - conj(b))
         v2f p0, q0, t0, p1, q1, t1;
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_add_f32 %0, %6, %7 neg_hi:[0,1]\n\t"
             "v_pk_add_f32 %3, %8, %9 neg_hi:[0,1]\n\t"
             "v_pk_add_f32 %1, %6, %7 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
@@ -475,7 +480,7 @@ GL_DEV void clamp_pairs2(v2f& a0, v2f& b0, v2f w0, float ma0, float mb0, v2f& a1
     v2f e0 = u0 + v0, f0 = u0 - v0, e1 = u1 + v1, f1 = u1 - v1;
     {   // o = conj(w) f;  a <- e + i o;  b <- conj(e - i o)
         v2f t0, t1;
-        asm("s_nop 0\n\t"
+        asm(GL_LEAD_NOP
             "v_pk_mul_f32 %0, %3, %6 op_sel_hi:[1,0]\n\t"
             "v_pk_mul_f32 %1, %5, %7 op_sel_hi:[1,0]\n\t"
             "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"

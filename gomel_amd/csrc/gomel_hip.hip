@@ -206,11 +206,17 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
     __syncthreads();
     const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr};
-    #ifdef GOMEL_EXP_NOBAR
-    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+        // Exchange synchronisation.  A stream of T <= 64 lanes lives inside ONE wave, whose LDS operations execute in program
+    // order: its exchanges need no s_barrier, only a compiler-level fence so that loads/stores are not reordered.  Wider
+    // streams (N = 4096: two waves) use the workgroup barrier.
+    auto sync = [] {
+#ifdef GOMEL_EXP_NOBAR
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #else
-    auto sync = [] { __syncthreads(); };
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
 #endif
+    };
 
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
     int seg = blockIdx.x * STREAMS + stream;

@@ -93,6 +93,59 @@ def run_workload(engine, fields, n_utt, frames, rank, steps, warmup, barrier):
     return elapsed, tm, out0
 
 
+def host_buffer_rate(engine, fields, n_utt, frames, rank):
+    """The drop-in entry point as Go would call it in bulk: host fp64 in, host fp64 out (plan + H2D + run + D2H through
+    pageable buffers).  Reported next to the HBM-resident figure, never as `value`."""
+    mels = make_inputs(fields, n_utt, frames, rank)
+    seeds = [1000 + rank * n_utt + u for u in range(n_utt)]
+    engine.from_mel_batch(mels[:2], None, seeds[:2])            # warm
+    t = time.perf_counter()
+    engine.from_mel_batch(mels, None, seeds)
+    return n_utt * frames / (time.perf_counter() - t)
+
+
+def config1(local_rank):
+    """BASELINE configs[0]: towav geometry (cmd/towav/main.go:30-40, 2 iterations) on a PNG.  The PNG named there (the
+    reference's README banner, 183x80) cannot run with NumMels = 192: the reference panics, the C ABI returns a status.  The
+    same pipeline then runs on the repository's 192-row fixture, on the GPU and through the C restatement on one host core."""
+    import ctypes
+    import gomel_amd
+    from gomel_amd import codec, _lib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gomel_oracle as go
+    import oracle_c
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    m = gomel_amd.NewMel()
+    m.MelFmin, m.MelFmax, m.YReverse, m.Window, m.NumMels, m.Resolut, m.GriffinLimIterations = 0, 16000, True, 1280, 192, 4096, 2
+    m.Device = local_rank
+    banner = os.path.join(gold, "reference_banner_183x80.png")
+    if os.path.exists(banner):
+        buf, _, _ = codec.loadpng(banner, True)
+        try:
+            m.FromMel(buf, seed=1)
+            out["reference_banner_png"] = "ran (unexpected)"
+        except gomel_amd.GomelError as e:
+            out["reference_banner_png"] = "183x80 pixels = %d pairs, not a multiple of 192: %s (the reference panics, mel/impl.go:366)" % (
+                len(buf), _lib.lib().gomel_strerror(e.status).decode())
+    buf, samples, sr = codec.loadpng(os.path.join(gold, "chirp_192.png"), True)
+    cfg = go.towav_config()
+    x0 = go.x0_splitmix(1, go.out_len(cfg, len(buf)))
+    m.FromMel(buf.copy(), x0=x0)
+    t = time.perf_counter()
+    for _ in range(20):
+        got = m.FromMel(buf.copy(), x0=x0)
+    gpu_ms = (time.perf_counter() - t) / 20 * 1e3
+    co = oracle_c.load()
+    t = time.perf_counter()
+    want, _ = co.from_mel(cfg, buf, x0)
+    cpu_ms = (time.perf_counter() - t) * 1e3
+    frames = len(buf) // 192
+    out.update({"fixture": "tests/golden/chirp_192.png (%d frames)" % frames, "gpu_ms_host_to_host": gpu_ms, "cpu_restatement_ms_1_thread": cpu_ms,
+                "rms_vs_cpu_restatement": float(np.sqrt(np.mean((got - want) ** 2)))})
+    return out
+
+
 def cpu_baseline(fields, frames, max_seconds_hint=30.0):
     """The C restatement of the reference algorithm (oracle/gomel_oracle.c) on the host cores: one 400-frame utterance
     per thread, same geometry and iteration count as the GPU workload."""
@@ -109,7 +162,7 @@ def cpu_baseline(fields, frames, max_seconds_hint=30.0):
     co.from_mel(cfg, small, go.x0_splitmix(0, go.out_len(cfg, len(small))))
     per_frame = (time.perf_counter() - t) / 4.0
     f_s = int(max(8, min(frames, (max_seconds_hint / 2.0) / max(per_frame, 1e-6))))
-    reps = 2 if f_s * per_frame < 8.0 else 1          # aim at 10-30 s of wall time on the sample
+    reps = int(min(8, max(1, math.ceil(10.0 / max(f_s * per_frame, 1e-3)))))   # aim at 10-30 s of wall time on the sample
     mels = [go.random_logmel(f_s, cfg.NumMels, seed=u) for u in range(cores * reps)]
     x0s = [go.x0_splitmix(1000 + u, go.out_len(cfg, len(m))) for u, m in enumerate(mels)]
     t = time.perf_counter()
@@ -176,6 +229,8 @@ def main():
                   "real_time_factor": fps2 * f2["Window"] / sr2}
         e2.close()
 
+    host_rate = host_buffer_rate(engine, fields, n_utt, frames, rank) if (rank == 0 and not args.no_single) else None
+    cfg1 = config1(local_rank) if (rank == 0 and not args.no_single) else None
     cpu = None
     if rank == 0 and not args.no_cpu:
         cpu = cpu_baseline(fields, frames)
@@ -204,6 +259,8 @@ def main():
                          "whole_job_frac": value / world * (I * algorithmic_bytes_per_frame_iter(N, hop) + fields["NumMels"] * 16 + hop * 8) / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
             "single_utterance": single,
+            "host_buffers_frames_per_s": host_rate,
+            "config1_towav_png_2_iters": cfg1,
             "table_broadcast_s": bcast_s,
             "device_ms": {"total": tm["total_ms"], "iterations": tm["iter_ms"], "dominant_kernel": tm["dom_ms"]},
             "output_rms": float(np.sqrt(np.mean(out0 * out0))),

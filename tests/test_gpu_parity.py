@@ -221,3 +221,30 @@ def test_extreme_magnitudes_and_negative_tune(oracle):
     mel = oracle.random_logmel(5, 192, seed=9)
     x0 = oracle.x0_splitmix(4, oracle.out_len(cfg, len(mel)))
     assert rms(m.FromMel(mel.copy(), x0=x0) - oracle.from_mel(cfg, mel.copy(), x0)) < RMS_TOL
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("SH", [1, 2, 4, 5, 8])
+def test_every_fused_instantiation(oracle, N, SH):
+    """k_gl_fused<N, SH> for all 15 instantiated (N, hop = SH*N/16) pairs, on a ragged batch so that streams sharing a
+    workgroup walk segments of different lengths, against the oracle and against the generic kernels."""
+    import gomel_amd
+    hop = SH * N // 16
+    K = {1024: 80, 2048: 160, 4096: 192}[N]
+    kw = dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=3)
+    cfg = oracle.MelConfig(**kw)
+    fr = [1, 2, 3, 5, 9, 17, 33, 4, 7, 21]
+    mels = [oracle.random_logmel(f, K, seed=N + SH + i) for i, f in enumerate(fr)]
+    x0s = [oracle.x0_splitmix(i, oracle.out_len(cfg, len(mm))) for i, mm in enumerate(mels)]
+    outs = {}
+    for path in (0, 1):
+        m = gomel_amd.NewMel()
+        for k, v in kw.items():
+            setattr(m, k, v)
+        if path:
+            m.engine().set_path(1)
+        outs[path] = m.FromMelBatch([mm.copy() for mm in mels], x0s)
+    for i, mm in enumerate(mels):
+        want = oracle.from_mel(cfg, mm.copy(), x0s[i])
+        assert rms(outs[0][i] - want) < RMS_TOL, (N, SH, i)
+        assert rms(outs[1][i] - want) < RMS_TOL, (N, SH, i)

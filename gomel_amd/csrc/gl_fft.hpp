@@ -102,20 +102,7 @@ template <bool INV, class V> GL_DEV void dft4_c(V& a0, V& a1, V& a2, V& a3) {
 #else
 #define GL_PKASM 0
 #endif
-#ifdef GOMEL_EXP_NOLEADNOP
-#define GL_LEAD_NOP ""
-#else
-#define GL_LEAD_NOP "s_nop 0\n\t"
-#endif
-#ifndef GL_PKASM_DFT4
-#define GL_PKASM_DFT4 GL_PKASM
-#endif
-#ifndef GL_PKASM_TW
-#define GL_PKASM_TW GL_PKASM
-#endif
-#ifndef GL_PKASM_CONST
-#define GL_PKASM_CONST GL_PKASM
-#endif
+#define GL_LEAD_NOP "s_nop 0\n\t"   // every block opens with one wait state (timing: free; it is not the bottleneck)
 
 // (a0, a1) <- (a0 * w0, a1 * w1), or * conj(w) when CONJ.  w may be VGPR pairs or (uniform constants) SGPR pairs.
 template <bool CONJ> GL_DEV void cmul2_asm(v2f& a0, v2f w0, v2f& a1, v2f w1) {
@@ -210,22 +197,22 @@ template <bool INV> GL_DEV void dft4_asm(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
 }
 
 template <bool INV, class V> GL_DEV void dft4(V& a0, V& a1, V& a2, V& a3) {
-    if constexpr (GL_PKASM_DFT4 && __is_same(V, v2f)) dft4_asm<INV>(a0, a1, a2, a3); else dft4_c<INV>(a0, a1, a2, a3);
+    if constexpr (GL_PKASM && __is_same(V, v2f)) dft4_asm<INV>(a0, a1, a2, a3); else dft4_c<INV>(a0, a1, a2, a3);
 }
 // (a0, a1) *= W^{+-1}-style constant twiddles (c - i s) forward / (c + i s) inverse
 template <bool INV, class V> GL_DEV void twc2(V& a0, double c0, double s0, V& a1, double c1, double s1) {
-    if constexpr (GL_PKASM_CONST && __is_same(V, v2f)) {
+    if constexpr (GL_PKASM && __is_same(V, v2f)) {
         // a*(c - i s) = a*conj(c + i s): CONJ form forward, plain form inverse, constant (c, s) in an SGPR pair
         cmul2_sconst_asm<!INV>(a0, v2f{(float)c0, (float)s0}, a1, v2f{(float)c1, (float)s1});
     } else { a0 = twc<INV>(a0, c0, s0); a1 = twc<INV>(a1, c1, s1); }
 }
 template <bool INV, class V> GL_DEV void twc1(V& a0, double c0, double s0) {
-    if constexpr (GL_PKASM_CONST && __is_same(V, v2f)) cmul1_sconst_asm<!INV>(a0, v2f{(float)c0, (float)s0});
+    if constexpr (GL_PKASM && __is_same(V, v2f)) cmul1_sconst_asm<!INV>(a0, v2f{(float)c0, (float)s0});
     else a0 = twc<INV>(a0, c0, s0);
 }
 // v[i] *= w[i] (or conj) for i in [1, n), in interleaved pairs
 template <bool CONJ, int STRIDE, int CNT, class V> GL_DEV void apply_tw(V* v, const V* w) {
-    if constexpr (GL_PKASM_TW && __is_same(V, v2f)) {
+    if constexpr (GL_PKASM && __is_same(V, v2f)) {
 #pragma unroll
         for (int q = 1; q + 1 < CNT; q += 2) cmul2_asm<CONJ>(v[q * STRIDE], w[q * STRIDE], v[(q + 1) * STRIDE], w[(q + 1) * STRIDE]);
         if constexpr ((CNT - 1) % 2 == 1) cmul1_asm<CONJ>(v[(CNT - 1) * STRIDE], w[(CNT - 1) * STRIDE]);

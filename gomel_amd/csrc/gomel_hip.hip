@@ -43,7 +43,6 @@ struct DevTables {
     const double* windowd; // [N]
     const BinRow* undo;    // [N/2]
     const BinRow* dom;     // [K]
-    const float* zeros;    // [N] zeros: target of "no tail here" loads in the fused kernel
 };
 
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
@@ -210,12 +209,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     // order: its exchanges need no s_barrier, only a compiler-level fence so that loads/stores are not reordered.  Wider
     // streams (N = 4096: two waves) use the workgroup barrier.
     auto sync = [] {
-#ifdef GOMEL_EXP_NOBAR
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#else
         if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
-#endif
     };
 
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
@@ -298,17 +293,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             xin[KEEP + jj] = xin_p[T * rx + t] + town[T * rn + t] * (in_next ? f_next : 0.f);
         }
         fft_forward<G>(v, my, t, tw, sync);
-#ifndef GOMEL_EXP_NOSPEC
         {
             v2f wn[8];
             make_wn<G>(wn, t, wt);
             spectral_apply<G>(v, t, mr, wn);
         }
-#else
-#pragma unroll
-        for (int s = 0; s < 8; s++) { v[s] *= mr.ma[s]; v[15 - s] *= mr.mb[s]; }
-        v[0].x += mr.m0 + mr.mn + wt.x;
-#endif
         fft_inverse<G>(v, my, t, tw, sync);
         if (active) {
             // overlap-add in registers: row j of this frame lands on accumulator row j (rows >= KEEP start a new sum);
@@ -606,7 +595,7 @@ static int upload_tables(gomel_handle* h) {
     auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     size_t o_win = carve(N * 4), o_tw1 = carve(C * 8), o_tw2 = carve(R2 * 8 * 8), o_wn = carve(C * 8);
     size_t o_tw1d = carve(C * 16), o_tw2d = carve(R2 * 8 * 16), o_wnd = carve(C * 16), o_wind = carve(N * 8);
-    size_t o_undo = carve(C * sizeof(BinRow)), o_dom = carve(K * sizeof(BinRow)), o_zero = carve(N * 4);
+    size_t o_undo = carve(C * sizeof(BinRow)), o_dom = carve(K * sizeof(BinRow));
     std::vector<char> host(off, 0);
     memcpy(&host[o_win], wf.data(), N * 4);
     memcpy(&host[o_tw1], tw1.data(), C * 8); memcpy(&host[o_tw2], tw2.data(), R2 * 8 * 8); memcpy(&host[o_wn], wn.data(), C * 8);
@@ -621,7 +610,6 @@ static int upload_tables(gomel_handle* h) {
     h->dt.tw1d = (const v2d*)(d + o_tw1d); h->dt.tw2d = (const v2d*)(d + o_tw2d); h->dt.wnd = (const v2d*)(d + o_wnd);
     h->dt.windowd = (const double*)(d + o_wind);
     h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
-    h->dt.zeros = (const float*)(d + o_zero);
     return GOMEL_OK;
 }
 

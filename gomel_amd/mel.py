@@ -12,7 +12,7 @@ import random
 import numpy as np
 
 from . import _lib
-from ._lib import GomelConfig, GomelError, GomelTiming, c_double_p, c_size_p, c_u64_p, check
+from ._lib import GomelConfig, GomelError, GomelTiming, c_double_p, check
 
 
 class ErrFileNotLoaded(Exception):

@@ -192,10 +192,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # One rank per GPU.  GOMEL_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: collectives run
+    # on CPU tensors and ranks wrap around the visible devices (the driver's multi-GPU runs use the default, nccl = RCCL).
+    backend = os.environ.get("GOMEL_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=coll_dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -208,13 +216,12 @@ def main():
     # table blob ("mel basis"): rank 0 builds, broadcast over RCCL/xGMI, every rank creates its handle from it
     from gomel_amd import dist as gdist
     t0 = time.perf_counter()
-    engine = gdist.create_engine_broadcast(lambda tables=None: build_engine(fields, local_rank, tables), rank, world,
-                                           device=torch.device("cuda", local_rank))
+    engine = gdist.create_engine_broadcast(lambda tables=None: build_engine(fields, local_rank, tables), rank, world, device=coll_dev)
     bcast_s = time.perf_counter() - t0
 
     elapsed, tm, out0 = run_workload(engine, fields, n_utt, frames, rank, args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -226,7 +226,7 @@ def main():
         elapsed = float(t.item())
 
     single = None
-    if rank == 0 and not args.no_single and args.workload != "cfg2":
+    if rank == 0 and world == 1 and not args.no_single and args.workload != "cfg2":
         d2, f2, u2, fr2, sr2 = WORKLOADS["cfg2"]
         e2 = build_engine(f2, local_rank)
         el2, tm2, _ = run_workload(e2, f2, u2, fr2, 0, max(3, args.steps), 1, lambda: None)
@@ -236,10 +236,11 @@ def main():
                   "real_time_factor": fps2 * f2["Window"] / sr2}
         e2.close()
 
-    host_rate = host_buffer_rate(engine, fields, n_utt, frames, rank) if (rank == 0 and not args.no_single) else None
-    cfg1 = config1(local_rank) if (rank == 0 and not args.no_single) else None
+    side = rank == 0 and world == 1 and not args.no_single       # side measurements and the CPU leg: N = 1 only
+    host_rate = host_buffer_rate(engine, fields, n_utt, frames, rank) if side else None
+    cfg1 = config1(local_rank) if side else None
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(fields, frames)
 
     if rank == 0:

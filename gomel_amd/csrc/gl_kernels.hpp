@@ -1,0 +1,472 @@
+// gl_kernels.hpp -- the HIP kernels of libgomel_hip.so (gfx950).  Included by gomel_hip.hip (host side + C ABI).
+// Reference steps replaced (file:line relative to the reference repository):
+//   k_mel_to_mag      spectral_denormalize mel/impl.go:421-427 + undomel :347-384 + undospectrum :386-408
+//   k_init_x          random init mel/mel.go:80-83 (explicit x0 or documented splitmix64 generator)
+//   k_gl_fused        one Griffin-Lim iteration (mel/mel.go:87-136) over runs of consecutive frames, hop = SH*N/16
+//   k_gl_frames/k_ola the same iteration for any even hop: per-frame kernel + overlap-add (mel/mel.go:112-125,135)
+//   k_finalize, k_add_tails   float -> double output (mel/mel.go:138)
+//   k_stft_mag, k_domel_log   ToMel mel/mel.go:46-74, domel mel/impl.go:310-345, spectral_normalize :410-419
+//   k_rfft, k_irfft   test hooks: what fft.FFTReal / fft.IFFT do per frame (mel/mel.go:95,116)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gl_fft.hpp"
+
+using namespace glfft;
+
+// =============================================================================================== device tables
+struct BinRow {  // one linear bin of undomel (or one mel band of domel): data-independent index math, built in fp64 on host
+    int32_t lo, hi;
+    int32_t mode;  // 0 copy band lo; 1 two-tap lo,hi with modlo; 2 sum lo..hi-1 divided by div
+    int32_t pad_;
+    double modlo, div;
+};
+
+struct DevTables {
+    const float* window;   // [N]
+    const v2f* tw1;        // fp32 twiddles (Griffin-Lim)
+    const v2f* tw2;
+    const v2f* wn;
+    const v2d* tw1d;       // fp64 twiddles (ToMel)
+    const v2d* tw2d;
+    const v2d* wnd;
+    const double* windowd; // [N]
+    const BinRow* undo;    // [N/2]
+    const BinRow* dom;     // [K]
+};
+
+GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
+    if (r.mode == 0) return e[r.lo];
+    if (r.mode == 1) return e[r.lo] * (1 - r.modlo) + e[r.hi] * r.modlo;
+    double tot = 0;
+    for (int k = r.lo; k < r.hi; k++) tot += e[k];
+    return tot / r.div;
+}
+
+// =============================================================================================== K1: log-mel -> target magnitudes
+// One block per frame.  mag[f][slot(k)] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from
+// channel 1 at bin N/2-1 (the only survivor of channel 1).  fp64 arithmetic, fp32 result.
+template <int N>
+__global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
+                                                    float* __restrict__ mag, float* __restrict__ nyq, int K,
+                                                    double tune_add, double tune_mul, double inv_n) {
+    constexpr int H = N / 2;
+    extern __shared__ double e_sh[];  // [2][K]
+    const int64_t f = blockIdx.x;
+    const double* m = mel + f * (int64_t)K * 2;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        e_sh[k] = exp(m[2 * k]);
+        e_sh[K + k] = exp(m[2 * k + 1]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const BinRow r = undo[i];
+        double v0 = (apply_row(r, e_sh) - tune_add) / tune_mul;
+        mag[f * H + mag_slot_index<Geo<N>>(i)] = (float)(fabs(v0) * inv_n);   // lane-slot order, see gl_fft.hpp
+        if (i == H - 1) {
+            double v1 = (apply_row(r, e_sh + K) - tune_add) / tune_mul;
+            nyq[f] = (float)(fabs(v1) * inv_n);
+        }
+    }
+}
+
+static void launch_mel_to_mag(int N, unsigned frames, size_t shmem, hipStream_t s, const double* mel, const BinRow* undo, float* mag, float* nyq,
+                              int K, double tune_add, double tune_mul) {
+    const double inv_n = 1.0 / (double)N;
+    if (N == 4096) hipLaunchKernelGGL(k_mel_to_mag<4096>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    else if (N == 2048) hipLaunchKernelGGL(k_mel_to_mag<2048>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    else hipLaunchKernelGGL(k_mel_to_mag<1024>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+}
+
+// =============================================================================================== K3: initial signal
+GL_DEV double splitmix_u01(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct UttDesc {  // one utterance of a batch
+    int64_t xoff;     // offset of its signal in the x / out buffers (samples)
+    int64_t fbase;    // index of its first frame in the frame-major buffers
+    int32_t frames;
+    int32_t has_x0;
+    int64_t len;      // L = N + (F-1) hop
+    uint64_t seed;
+};
+
+template <class OutT>
+__global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, const double* __restrict__ x0, OutT* __restrict__ x) {
+    const UttDesc u = utts[blockIdx.y];
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+        double v = u.has_x0 ? x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
+        x[u.xoff + n] = (OutT)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, double* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (double)x[i];
+}
+
+// =============================================================================================== generic path: frames kernel
+// WG = 128 lanes = 128/T frame streams.  Each stream: gather frame * Hann -> rFFT -> clamp -> irFFT -> * Hann -> yw[frame][N].
+template <int N>
+__global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, const int64_t* __restrict__ frame_xoff,
+                                                   const float* __restrict__ mag, const float* __restrict__ nyq,
+                                                   float* __restrict__ yw, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;  // keep the lanes in the barriers; results are dropped
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
+    auto sync = [] { __syncthreads(); };
+
+    const v2f* xs = reinterpret_cast<const v2f*>(x + frame_xoff[frame]);  // hop and offsets are even: 8-byte aligned
+    const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
+    v2f v[16], w[16], wn[8];
+    MagRegs mr;
+    load_mags<G>(mr, t, mag + frame * G::C, nyq + frame);
+    load_wn<G>(wn, t, tb.wn);
+#pragma unroll
+    for (int j = 0; j < 16; j++) { w[j] = w2[t + G::T * j]; v[j] = xs[t + G::T * j] * w[j]; }
+    fft_forward<G>(v, my, t, tw, sync);
+    spectral_apply<G>(v, t, mr, wn);
+    fft_inverse<G>(v, my, t, tw, sync);
+    if (live) {
+        v2f* ys = reinterpret_cast<v2f*>(yw + frame * N);
+#pragma unroll
+        for (int j = 0; j < 16; j++) ys[t + G::T * j] = v[j] * w[j];
+    }
+}
+
+// x'[n] = sum over the frames covering n of yw[k][n - k*hop], in frame order (mel/mel.go:115-125).
+__global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, const float* __restrict__ yw, float* __restrict__ xn,
+                                             int N, int hop) {
+    const UttDesc u = utts[blockIdx.y];
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
+        int64_t k1 = n / hop;
+        if (k1 > u.frames - 1) k1 = u.frames - 1;
+        float acc = 0.f;
+        for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
+        xn[u.xoff + n] = acc;
+    }
+}
+
+
+// =============================================================================================== fused path
+// One stream of T lanes walks a SEGMENT of G consecutive frames of one utterance.  With hop = SH*(N/16) the frame's
+// sample pairs sit in registers by "row" (row j = pairs t + T*j, N/16 samples), and moving to the next frame is a shift
+// by SH registers: SH new rows are loaded (hop samples), SH finished rows of the overlap-add are stored (hop samples).
+// So per frame-iteration the kernel reads hop*4 + (N/2+1)*4 bytes and writes hop*4 -- the algorithmic minimum.
+// Segment boundaries: a segment OWNS the samples [s0, s0 + G*hop) (the last one of an utterance: to the utterance's
+// end).  What its frames add beyond that (N - hop samples, the next segment's head) goes to a per-segment TAIL buffer;
+// whoever reads a head sample next iteration adds x + tail (two plain loads, deterministic, no atomics).
+struct SegDesc {
+    int64_t s0;       // offset of the segment's first sample in the x buffers
+    int64_t frame0;   // global index of its first frame (row of mag / nyq)
+    int32_t G;        // frames in the segment
+    int32_t has_prev; // not the first segment of its utterance -> add tail[seg-1] over the first 16-SH rows
+    int32_t has_next; // not the last -> rows >= G*SH belong to the next segment: read x + tail[seg], write tail[seg]
+    int32_t pad_;
+};
+
+constexpr int kFusedThreads = 256;
+
+template <int N, int SH>
+__global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __restrict__ x_in, const float* __restrict__ tail_in,
+                                                     float* __restrict__ x_out, float* __restrict__ tail_out,
+                                                     const SegDesc* __restrict__ segs, int n_segs, int g_max,
+                                                     const float* __restrict__ mag, const float* __restrict__ nyq, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = kFusedThreads / T, KEEP = 16 - SH, TAIL_PAIRS = KEEP * T;  // tail = (N - hop)/2 pairs
+    // LDS: per-stream exchange areas, then the tables every stream of the WG shares (TW1, TW2, window as pairs)
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
+    v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
+    v2f* tw2_l = tw1_l + G::TW1_N;
+    v2f* win_l = tw2_l + G::TW2_N;
+    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1[i];
+    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2[i];
+    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
+    __syncthreads();
+    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr};
+        // Exchange synchronisation.  A stream of T <= 64 lanes lives inside ONE wave, whose LDS operations execute in program
+    // order: its exchanges need no s_barrier, only a compiler-level fence so that loads/stores are not reordered.  Wider
+    // streams (N = 4096: two waves) use the workgroup barrier.
+    auto sync = [] {
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    int seg = blockIdx.x * STREAMS + stream;
+    const bool live = seg < n_segs;
+    if (!live) seg = n_segs - 1;
+    SegDesc d = segs[seg];
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    if constexpr (T >= 64) {  // whole-wave streams: the descriptor is wave-uniform -> keep it (and all row logic) in SGPRs
+        d.G = __builtin_amdgcn_readfirstlane(d.G);
+        d.has_prev = __builtin_amdgcn_readfirstlane(d.has_prev);
+        d.has_next = __builtin_amdgcn_readfirstlane(d.has_next);
+        seg = __builtin_amdgcn_readfirstlane(seg);
+    }
+
+    // Bases = kernel-argument pointer + offset.  Streams of T >= 64 lanes are whole waves, so the segment (hence every
+    // offset) is wave-uniform and is moved to SGPRs; lane offsets are then 32-bit.  (T = 32: two streams share a wave.)
+    constexpr bool WU = (T >= 64);
+    auto uo = [](long long v) { if constexpr (WU) return uniform_i64(v); else return v; };
+    const int seg_prev = d.has_prev ? seg - 1 : seg;                          // clamped: only read with flag f_prev
+    const v2f* xin_p = reinterpret_cast<const v2f*>(x_in) + uo(d.s0 / 2);     // row r, lane t -> xin_p[T*r + t]
+    v2f* xout_p = reinterpret_cast<v2f*>(x_out) + uo(d.s0 / 2);
+    const v2f* tprev = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg_prev * TAIL_PAIRS);
+    const v2f* town = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg * TAIL_PAIRS);
+    v2f* tout = reinterpret_cast<v2f*>(tail_out) + uo((int64_t)seg * TAIL_PAIRS);
+    const float* mag_p = mag + uo(d.frame0 * G::C);
+    const float* nyq_p = nyq + uo(d.frame0);
+    const float f_prev = d.has_prev ? 1.f : 0.f, f_next = d.has_next ? 1.f : 0.f;
+    const int rows_owned = d.G * SH;  // rows >= this belong to the next segment's head
+    if constexpr (STREAMS > 1) {  // streams of one WG share the barriers: loop to the longest segment among them
+        __shared__ int g_sh[STREAMS];
+        if (t == 0) g_sh[stream] = live ? d.G : 0;
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < STREAMS; i++) m = max(m, g_sh[i]);
+        g_max = m;
+    } else {
+        g_max = d.G;
+    }
+
+    v2f xin[16], acc[KEEP];
+    const v2f* wl = win_l + t;  // window pair of row j: wl[T*j]
+    const v2f wt = tb.wn[t];
+    // Tail terms are loaded unconditionally (clamped row, times a 0/1 flag) so that all loads of a frame go out together
+    // instead of one branch + vmcnt(0) each; tail buffers are zero-filled at allocation, unused tails stay zero.
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        v2f a = xin_p[T * j + t];
+        if (j < KEEP) a += tprev[T * j + t] * f_prev;
+        const int rn = j >= rows_owned ? j - rows_owned : 0;   // < KEEP because G >= ceil(KEEP/SH) whenever has_next
+        a += town[T * rn + t] * (j >= rows_owned ? f_next : 0.f);
+        xin[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < KEEP; j++) acc[j] = v2f{0.f, 0.f};
+
+    for (int g = 0; g < g_max; g++) {
+        const bool active = live && g < d.G;
+        const int gg = g < d.G ? g : d.G - 1;
+        MagRegs mr;
+        load_mags<G>(mr, t, mag_p + (int64_t)gg * G::C, nyq_p + gg);
+        v2f v[16];
+        // all 16 window reads go out back to back (one LDS round trip, not sixteen), then the multiplies
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = wl[T * j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] *= xin[j];
+        // slide the input window now: the next frame's SH new rows (hop samples) load behind the two FFTs
+#pragma unroll
+        for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];
+        const bool more = g + 1 < d.G;
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) {
+            const int row = (g + 1) * SH + KEEP + jj;
+            const int rx = more ? row : 0;                                   // clamped: the value is unused when !more
+            const bool in_next = more && row >= rows_owned;
+            const int rn = in_next ? row - rows_owned : 0;
+            xin[KEEP + jj] = xin_p[T * rx + t] + town[T * rn + t] * (in_next ? f_next : 0.f);
+        }
+        fft_forward<G>(v, my, t, tw, sync);
+        {
+            v2f wn[8];
+            make_wn<G>(wn, t, wt);
+            spectral_apply<G>(v, t, mr, wn);
+        }
+        fft_inverse<G>(v, my, t, tw, sync);
+        if (active) {
+            // overlap-add in registers: row j of this frame lands on accumulator row j (rows >= KEEP start a new sum);
+            // the first SH rows are finished by this frame and leave, the rest shift down by SH for the next frame.
+            v2f* xo = xout_p + T * (g * SH);
+#pragma unroll
+            for (int j = 0; j < SH; j++) {
+                const v2f y = v[j] * wl[T * j];
+                xo[T * j + t] = (j < KEEP) ? acc[j] + y : y;
+            }
+            v2f nacc[KEEP];
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) {
+                const v2f y = v[j + SH] * wl[T * (j + SH)];
+                nacc[j] = (j + SH < KEEP) ? acc[j + SH] + y : y;
+            }
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) acc[j] = nacc[j];
+            if (g == d.G - 1) {
+                // what is left belongs past the owned range: next segment's head (tail buffer) or the utterance's end
+                if (d.has_next) {
+#pragma unroll
+                    for (int j = 0; j < KEEP; j++) tout[T * j + t] = acc[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KEEP; j++) xout_p[T * (rows_owned + j) + t] = acc[j];
+                }
+            }
+        }
+    }
+}
+
+// out += tails (fp64), after k_finalize has converted the owned samples
+__global__ __launch_bounds__(256) void k_add_tails(const SegDesc* __restrict__ segs, const float* __restrict__ tail, double* __restrict__ out,
+                                                   int tail_len, int hop) {
+    const SegDesc d = segs[blockIdx.x];
+    if (!d.has_next) return;
+    double* o = out + d.s0 + (int64_t)d.G * hop;
+    const float* tp = tail + (int64_t)blockIdx.x * tail_len;
+    for (int i = threadIdx.x; i < tail_len; i += blockDim.x) o[i] += (double)tp[i];
+}
+
+
+// =============================================================================================== ToMel (forward path), fp64
+// gossp STFT (window + fft.FFTReal, mel/mel.go:52) -> |S[j]|, j in [0, N/2]  (mel/mel.go:55-63 pairs |S[j]| with
+// |S[N-1-j]| = |S[j+1]|, so one array of N/2+1 magnitudes serves both channels).  fp64 because ln() of bins near the
+// 1e-5 floor needs more dynamic range than an fp32 FFT keeps.
+template <int N>
+__global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wave, double* __restrict__ smag, int64_t n_frames, int hop, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    auto sync = [] { __syncthreads(); };
+    const double* xs = wave + frame * hop;
+    v2d v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = 2 * (t + G::T * j);
+        v[j] = v2d{xs[p] * tb.windowd[p], xs[p + 1] * tb.windowd[p + 1]};
+    }
+    fft_forward<G>(v, my, t, tw, sync);
+    if (!live) return;
+    double* out = smag + frame * (G::C + 1);
+    const bool is0 = (t == 0);
+    const v2d dc = v[0];
+    if (is0) {  // same slot permutation as lane0_permute, fp64
+        v2d a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[i] = v[i]; b[i] = v[8 + i]; }
+        v[0] = a[4]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        v[8] = b[4]; v[9] = b[5]; v[10] = b[6]; v[11] = b[7]; v[12] = a[5]; v[13] = a[6]; v[14] = a[7]; v[15] = a[4];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        const v2d a = v[s], b = v[15 - s], wk = tb.wnd[k];
+        const v2d bc = v2d{b.x, -b.y};
+        const v2d p = a + bc, d = a - bc;
+        const v2d q = cmul(wk, v2d{d.y, -d.x});
+        const v2d xk = p + q, xc = p - q;  // 2 X[k], 2 conj(X[C-k])
+        out[k] = 0.5 * hypot(xk.x, xk.y);
+        out[G::C - k] = 0.5 * hypot(xc.x, xc.y);
+    }
+    if (is0) { out[0] = fabs(dc.x + dc.y); out[G::C] = fabs(dc.x - dc.y); }
+}
+
+// domel (mel/impl.go:310-345) + spectral_normalize (mel/impl.go:410-419): one block per frame, one thread per band.
+__global__ __launch_bounds__(256) void k_domel_log(const double* __restrict__ smag, const BinRow* __restrict__ dom, double* __restrict__ out,
+                                                   int K, int H) {
+    const int64_t f = blockIdx.x;
+    const double* m = smag + f * (H + 1);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const BinRow r = dom[i];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            double v = apply_row(r, m + c);  // channel 1 is the same spectrum one bin up: |S[N-1-j]| = |S[j+1]|
+            if (v < 1e-5) v = 1e-5;
+            out[(f * K + i) * 2 + c] = log(v);
+        }
+    }
+}
+
+// =============================================================================================== test hooks: plain rfft / irfft
+template <int N>
+__global__ __launch_bounds__(128) void k_rfft(const float* __restrict__ frames, float* __restrict__ spec, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
+    auto sync = [] { __syncthreads(); };
+    const v2f* xs = reinterpret_cast<const v2f*>(frames + frame * N);
+    v2f v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j];
+    fft_forward<G>(v, my, t, tw, sync);
+    if (!live) return;
+    v2f* out = reinterpret_cast<v2f*>(spec + frame * (N + 2));
+    const bool is0 = (t == 0);
+    v2f dc = v[0];
+    lane0_permute<G>(v, is0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        v2f a = v[s], b = v[15 - s], wk = tb.wn[k];
+        v2f bc = v2f{b.x, -b.y};
+        v2f p = a + bc, d = a - bc;
+        v2f q = cmul(wk, v2f{d.y, -d.x});
+        v2f xk = (p + q) * 0.5f, xc = (p - q) * 0.5f;
+        out[k] = xk;
+        out[G::C - k] = v2f{xc.x, -xc.y};
+    }
+    if (is0) { out[0] = v2f{dc.x + dc.y, 0.f}; out[G::C] = v2f{dc.x - dc.y, 0.f}; }
+}
+
+template <int N>
+__global__ __launch_bounds__(128) void k_irfft(const float* __restrict__ spec, float* __restrict__ frames, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
+    auto sync = [] { __syncthreads(); };
+    const v2f* in = reinterpret_cast<const v2f*>(spec + frame * (N + 2));
+    const bool is0 = (t == 0);
+    const float sc = 1.0f / (float)N;
+    v2f v[16];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        v2f u = in[k] * sc, y2 = in[G::C - k] * sc, wk = tb.wn[k];
+        v2f vv = v2f{y2.x, -y2.y};
+        v2f e = u + vv, o = cmulc(u - vv, wk);
+        v[s] = v2f{e.x - o.y, e.y + o.x};
+        v[15 - s] = v2f{e.x + o.y, o.x - e.y};
+    }
+    v2f dc = v2f{0.f, 0.f};
+    if (is0) { float y0 = in[0].x * sc, yn = in[G::C].x * sc; dc = v2f{y0 + yn, y0 - yn}; }
+    lane0_unpermute<G>(v, is0, dc);
+    fft_inverse<G>(v, my, t, tw, sync);
+    if (live) {
+        v2f* ys = reinterpret_cast<v2f*>(frames + frame * N);
+#pragma unroll
+        for (int j = 0; j < 16; j++) ys[t + G::T * j] = v[j];
+    }
+}
+

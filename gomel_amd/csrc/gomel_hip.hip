@@ -535,7 +535,9 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
         b->total_frames += d.frames; b->total_pairs += (int64_t)n_pairs[u];
         b->max_len = std::max(b->max_len, d.len);
     }
-    b->fast = (h->path_mode != 1 && fused_applicable(c)) ? 1 : 0;
+    // Path choice: the fused kernel walks >= 3 consecutive frames per stream, which only pays once there are enough frames
+    // to fill the chip; one short utterance (<= 512 frames, measured crossover) is faster with every frame in parallel.
+    b->fast = (h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames > 512)) ? 1 : 0;
     const int I = c.griffin_lim_iterations;
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };

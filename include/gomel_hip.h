@@ -116,7 +116,8 @@ int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t); /* synchronises */
 int gomel_batch_sync(gomel_batch* b);
 int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap);
 int gomel_batch_destroy(gomel_batch* b);
-/* 0 = let the library choose; 1 = force the generic kernels; 2 = require the fused kernel (error if not applicable) */
+/* 0 = let the library choose (fused kernel when the hop allows it and the batch has more than 512 frames);
+ * 1 = force the generic kernels; 2 = require the fused kernel (error if the hop is not SH*Resolut/16, SH in 1,2,4,5,8) */
 int gomel_set_path(gomel_handle* h, int mode);
 
 /* (*Mel).ToMel, mel/mel.go:46-74 = pad + gossp STFT + |S[j]|,|S[N-1-j]| + domel + ln(max(v,1e-5)). */

@@ -23,7 +23,7 @@ def rms(a):
 
 
 def make_mel(geom, iters, path=0, **kw):
-    """path: 0 = library's choice (fused kernel when hop = SH*N/16), 1 = force the generic kernels."""
+    """path: 0 = library's choice, 1 = force the generic kernels, 2 = require the fused kernel (hop = SH*N/16)."""
     import gomel_amd
     m = gomel_amd.NewMel()
     for k, v in dict(GEOMS[geom], GriffinLimIterations=iters, **kw).items():
@@ -67,7 +67,7 @@ def test_target_magnitudes(oracle, geom):
     assert np.max(np.abs(got - want) / (np.abs(want) + 1e-30)) < 2e-7
 
 
-@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("path", [2, 1])
 @pytest.mark.parametrize("geom,frames", [("T", 4), ("T", 9), ("S", 8), ("S", 3), ("D", 6), ("T", 1), ("T", 40), ("S", 70), ("D", 33)])
 @pytest.mark.parametrize("iters", [0, 1, 2, 60])
 def test_from_mel_matches_oracle(oracle, geom, frames, iters, path):
@@ -101,7 +101,7 @@ def test_seed_generator_matches_documented_splitmix(oracle):
     assert rms(a - b) < 1e-6
 
 
-@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("path", [2, 1])
 def test_ragged_batch_equals_single_calls(oracle, path):
     m = make_mel("S", 3, path)
     cfg = ocfg(oracle, "S", 3)
@@ -157,7 +157,7 @@ def test_fused_segments_are_invisible(oracle, monkeypatch):
     ref = make_mel("T", 4, path=1).FromMelBatch([mm.copy() for mm in mels], x0s)
     for seg in ("3", "4", "7", "64"):
         monkeypatch.setenv("GOMEL_SEG_FRAMES", seg)
-        got = make_mel("T", 4).FromMelBatch([mm.copy() for mm in mels], x0s)
+        got = make_mel("T", 4, path=2).FromMelBatch([mm.copy() for mm in mels], x0s)
         for a, b in zip(got, ref):
             assert rms(a - b) < 2e-6, seg
     want = oracle.from_mel(cfg, mels[0].copy(), x0s[0])
@@ -173,6 +173,11 @@ def test_hops_fused_and_generic(oracle, hop):
     for k, v in kw.items():
         setattr(m, k, v)
     cfg = oracle.MelConfig(**kw)
+    if hop * 16 % 4096 == 0 and hop * 16 // 4096 in (1, 2, 4, 5, 8):
+        m.engine().set_path(2)                  # must be accepted: these hops have a fused instantiation
+    else:
+        with pytest.raises(gomel_amd.GomelError):
+            m.engine().set_path(2)              # 768 = 3 rows and 100 are served by the generic kernels only
     mel = oracle.random_logmel(21, 192, seed=hop)
     x0 = oracle.x0_splitmix(hop, oracle.out_len(cfg, len(mel)))
     want = oracle.from_mel(cfg, mel.copy(), x0)
@@ -180,7 +185,7 @@ def test_hops_fused_and_generic(oracle, hop):
     assert rms(got - want) < RMS_TOL
 
 
-@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("path", [2, 1])
 @pytest.mark.parametrize("geom", ["T", "S"])
 def test_zero_signal_takes_the_phase_zero_rule(oracle, geom, path):
     """x0 = 0 makes every re-STFT bin exactly zero: cmplx.Phase(0) = 0, so the reference imposes Y = M (mel.go:100-101).
@@ -241,10 +246,27 @@ def test_every_fused_instantiation(oracle, N, SH):
         m = gomel_amd.NewMel()
         for k, v in kw.items():
             setattr(m, k, v)
-        if path:
-            m.engine().set_path(1)
+        m.engine().set_path(1 if path else 2)
         outs[path] = m.FromMelBatch([mm.copy() for mm in mels], x0s)
     for i, mm in enumerate(mels):
         want = oracle.from_mel(cfg, mm.copy(), x0s[i])
         assert rms(outs[0][i] - want) < RMS_TOL, (N, SH, i)
         assert rms(outs[1][i] - want) < RMS_TOL, (N, SH, i)
+
+
+def test_automatic_path_choice(oracle):
+    """Library's choice: one short utterance (<= 512 frames) runs the generic kernels (every frame in parallel), bigger
+    batches the fused kernel; both agree with the oracle."""
+    import gomel_amd
+    m = make_mel("T", 2)
+    e = m.engine()
+    for n_utt, frames, want_fast in ((1, 300, 0), (4, 300, 1)):
+        b = gomel_amd.Batch(e, [frames * 192] * n_utt)
+        mels = [oracle.random_logmel(frames, 192, seed=u) for u in range(n_utt)]
+        b.upload(mels, None, list(range(n_utt)))
+        tm = b.run_timed()
+        assert tm["fast_path"] == want_fast and tm["frames"] == n_utt * frames
+        out = b.download()[0]
+        b.close()
+        cfg = ocfg(oracle, "T", 2)
+        assert rms(out - oracle.from_mel(cfg, mels[0].copy(), oracle.x0_splitmix(0, len(out)))) < RMS_TOL

@@ -87,6 +87,7 @@ int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap);
 int gomel_set_window(gomel_handle* h, const double* window, size_t n);
 int gomel_get_window(const gomel_handle* h, double* window, size_t cap);
 
+/* Destroy every gomel_batch created from the handle first. */
 int gomel_destroy(gomel_handle* h);
 
 /* len(reconstructedSignal), mel/mel.go:80.  0 on bad arguments. */

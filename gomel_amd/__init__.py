@@ -6,5 +6,6 @@ on a machine without a GPU works, calling into it raises.
 """
 from .mel import (Batch, Engine, ErrFileNotLoaded, LoadFlac, LoadWav, Mel, NewMel, SaveWav)  # noqa: F401
 from ._lib import GomelConfig, GomelError  # noqa: F401
+from .phase import NewPhase, Phase  # noqa: F401
 
-__all__ = ["NewMel", "Mel", "Engine", "Batch", "ErrFileNotLoaded", "LoadWav", "LoadFlac", "SaveWav", "GomelConfig", "GomelError"]
+__all__ = ["NewMel", "Mel", "Engine", "Batch", "ErrFileNotLoaded", "LoadWav", "LoadFlac", "SaveWav", "GomelConfig", "GomelError", "NewPhase", "Phase"]

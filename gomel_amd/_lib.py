@@ -52,6 +52,10 @@ SYMBOLS = {
     "gomel_set_path": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_to_mel_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
     "gomel_to_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
+    "gomel_phase_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_int32, ctypes.c_size_t]),
+    "gomel_phase_out_len": (ctypes.c_size_t, [_cfg_p, ctypes.c_int32, ctypes.c_size_t]),
+    "gomel_to_phase": (ctypes.c_int, [_vp, ctypes.c_int32, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
+    "gomel_from_phase": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
     "gomel_pad_len": (ctypes.c_size_t, [ctypes.c_size_t, ctypes.c_int32]),
     "gomel_is_padded": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32]),
     "gomel_rfft_frames": (ctypes.c_int, [_vp, c_float_p, ctypes.c_size_t, c_float_p]),

@@ -376,19 +376,19 @@ template <class G> GL_DEV int slot_bin(int t, int s) {
     return s == 0 ? G::C / 2 : (s < 4 ? G::B3 * s : G::B3 / 2 + G::B3 * (s - 4));
 }
 
-template <class G> GL_DEV void lane0_permute(v2f (&v)[16], bool is0) {
+template <class G, class V> GL_DEV void lane0_permute(V (&v)[16], bool is0) {
     // (PA | PB) <- (VA | VB):  PA = [VA4 VA1 VA2 VA3 VB0 VB1 VB2 VB3], PB = [VB4 VB5 VB6 VB7 VA5 VA6 VA7 VA4]
     if (is0) {
-        v2f a[8], b[8];
+        V a[8], b[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { a[i] = v[i]; b[i] = v[8 + i]; }
         v[0] = a[4]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
         v[8] = b[4]; v[9] = b[5]; v[10] = b[6]; v[11] = b[7]; v[12] = a[5]; v[13] = a[6]; v[14] = a[7]; v[15] = a[4];
     }
 }
-template <class G> GL_DEV void lane0_unpermute(v2f (&v)[16], bool is0, v2f dc) {
+template <class G, class V> GL_DEV void lane0_unpermute(V (&v)[16], bool is0, V dc) {
     if (is0) {
-        v2f pa[8], pb[8];
+        V pa[8], pb[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { pa[i] = v[i]; pb[i] = v[8 + i]; }
         v[0] = dc; v[4] = pa[0]; v[5] = pb[4]; v[6] = pb[5]; v[7] = pb[6];

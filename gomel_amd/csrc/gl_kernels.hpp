@@ -6,6 +6,7 @@
 //   k_gl_frames/k_ola the same iteration for any even hop: per-frame kernel + overlap-add (mel/mel.go:112-125,135)
 //   k_finalize, k_add_tails   float -> double output (mel/mel.go:138)
 //   k_stft_mag, k_domel_log   ToMel mel/mel.go:46-74, domel mel/impl.go:310-345, spectral_normalize :410-419
+//   k_phase_stft, k_phase_istft, k_phase_ola   phase.ToPhase / FromPhase, phase/phase.go:41-155
 //   k_rfft, k_irfft   test hooks: what fft.FFTReal / fft.IFFT do per frame (mel/mel.go:95,116)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -360,13 +361,7 @@ __global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wav
     double* out = smag + frame * (G::C + 1);
     const bool is0 = (t == 0);
     const v2d dc = v[0];
-    if (is0) {  // same slot permutation as lane0_permute, fp64
-        v2d a[8], b[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { a[i] = v[i]; b[i] = v[8 + i]; }
-        v[0] = a[4]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-        v[8] = b[4]; v[9] = b[5]; v[10] = b[6]; v[11] = b[7]; v[12] = a[5]; v[13] = a[6]; v[14] = a[7]; v[15] = a[4];
-    }
+    lane0_permute<G>(v, is0);
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int k = slot_bin<G>(t, s);
@@ -394,6 +389,118 @@ __global__ __launch_bounds__(256) void k_domel_log(const double* __restrict__ sm
             if (v < 1e-5) v = 1e-5;
             out[(f * K + i) * 2 + c] = log(v);
         }
+    }
+}
+
+
+// =============================================================================================== package phase (fp64)
+// (*Phase).ToPhase, phase/phase.go:41-72: gossp STFT, then per bin j < N/2 the pair (Im S[j+1], Re S[N-1-j]) -- for a real
+// frame Re S[N-1-j] = Re S[j+1] -- and `shrink` to the first NumFreqs pairs of every frame (phase/impl.go:383-391).
+template <int N>
+__global__ __launch_bounds__(128) void k_phase_stft(const double* __restrict__ wave, double* __restrict__ out, int64_t n_frames, int hop, int nf,
+                                                    DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    auto sync = [] { __syncthreads(); };
+    const double* xs = wave + frame * hop;
+    v2d v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int p = 2 * (t + G::T * j);
+        v[j] = v2d{xs[p] * tb.windowd[p], xs[p + 1] * tb.windowd[p + 1]};
+    }
+    fft_forward<G>(v, my, t, tw, sync);
+    if (!live) return;
+    v2d* o = reinterpret_cast<v2d*>(out) + frame * nf;
+    const bool is0 = (t == 0);
+    const v2d dc = v[0];
+    lane0_permute<G>(v, is0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        const v2d a = v[s], b = v[15 - s], wk = tb.wnd[k];
+        const v2d bc = v2d{b.x, -b.y};
+        const v2d p = a + bc, d = a - bc;
+        const v2d q = cmul(wk, v2d{d.y, -d.x});
+        const v2d xk = p + q, xc = p - q;              // 2 S[k], 2 conj(S[C-k])
+        if (k - 1 < nf) o[k - 1] = v2d{0.5 * xk.y, 0.5 * xk.x};
+        if (G::C - k - 1 < nf) o[G::C - k - 1] = v2d{-0.5 * xc.y, 0.5 * xc.x};
+    }
+    if (is0 && G::C - 1 < nf) o[G::C - 1] = v2d{0.0, dc.x - dc.y};   // bin N/2 is real
+}
+
+// (*Phase).FromPhase up to the overlap-add, phase/phase.go:137-147 + 74-94 + the IFFT of ISTFT (:104): `grow` repeats a frame's
+// last pair up to N/2 bins (phase/impl.go:392-404), bin k = j+1 gets realm0 + i realn1, bin 0 stays 0, bin N/2 is real.
+template <int N>
+__global__ __launch_bounds__(128) void k_phase_istft(const double* __restrict__ pairs, double* __restrict__ yw, int64_t n_frames, int nf,
+                                                     DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    auto sync = [] { __syncthreads(); };
+    const v2d* in = reinterpret_cast<const v2d*>(pairs) + frame * nf;
+    const bool is0 = (t == 0);
+    const double sc = 1.0 / (double)N;
+    auto bin = [&](int kk) {                         // spectrum value of bin kk in [1, C-1] (or the real part for kk = C)
+        const int j = kk - 1;
+        const v2d pr = in[j < nf ? j : nf - 1];       // (realn1, realm0)
+        return v2d{pr.y * sc, pr.x * sc};
+    };
+    v2d v[16];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        const v2d u = bin(k), y2 = bin(G::C - k), wk = tb.wnd[k];
+        const v2d vv = v2d{y2.x, -y2.y};
+        const v2d e = u + vv, o = cmulc(u - vv, wk);
+        v[s] = v2d{e.x - o.y, e.y + o.x};
+        v[15 - s] = v2d{e.x + o.y, o.x - e.y};
+    }
+    v2d dc = v2d{0.0, 0.0};
+    if (is0) { const double yn = bin(G::C).x; dc = v2d{yn, -yn}; }   // Y[0] = 0, Y[N/2] = realm0
+    lane0_unpermute<G>(v, is0, dc);
+    fft_inverse<G>(v, my, t, tw, sync);
+    if (live) {
+        v2d* ys = reinterpret_cast<v2d*>(yw + frame * N);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int p = 2 * (t + G::T * j);
+            ys[t + G::T * j] = v2d{v[j].x * tb.windowd[p], v[j].y * tb.windowd[p + 1]};
+        }
+    }
+}
+
+// Overlap-add with the window-square normalisation of phase.ISTFT (phase/phase.go:103-131): divide where the window sum
+// exceeds `thr` (half its maximum), fade proportionally below, leave samples with no window energy; then VolumeBoost.
+__global__ __launch_bounds__(256) void k_phase_ola(const double* __restrict__ yw, double* __restrict__ out, int64_t len, int frames, int N, int hop,
+                                                   const double* __restrict__ window, double thr, double boost) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < len; n += (int64_t)gridDim.x * blockDim.x) {
+        int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
+        int64_t k1 = n / hop;
+        if (k1 > frames - 1) k1 = frames - 1;
+        double acc = 0.0, ws = 0.0;
+        for (int64_t k = k0; k <= k1; k++) {
+            const int j = (int)(n - k * hop);
+            acc += yw[k * N + j];
+            ws += window[j] * window[j];
+        }
+        if (ws > thr) acc /= ws;
+        else if (ws > 1e-21) acc = acc / ws * (ws / thr);
+        if (boost != 0.0) acc *= boost;
+        out[n] = acc;
     }
 }
 

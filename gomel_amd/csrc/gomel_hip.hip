@@ -756,4 +756,92 @@ int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pair
     return rc;
 }
 
+// ----------------------------------------------------------------------------------------------- package phase
+size_t gomel_phase_pairs(const gomel_config* c, int32_t num_freqs, size_t n) {   // len(ToPhase(buf))
+    if (!c || c->window <= 0 || c->resolut <= 0 || num_freqs <= 0) return 0;
+    size_t p = gomel_pad_len(n, c->window);
+    if (p < (size_t)c->resolut) return 0;
+    long F = (long)((double)(p - (size_t)c->resolut) / (double)c->window) + 1;
+    size_t nf = (size_t)std::min<int64_t>(num_freqs, c->resolut / 2);
+    return (size_t)F * nf;
+}
+
+size_t gomel_phase_out_len(const gomel_config* c, int32_t num_freqs, size_t n_pairs) {
+    if (!c || num_freqs <= 0 || n_pairs == 0 || n_pairs % (size_t)num_freqs) return 0;
+    return (size_t)c->resolut + (n_pairs / (size_t)num_freqs - 1) * (size_t)c->window;
+}
+
+int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+    if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
+    const gomel_config& c = h->cfg;
+    const int N = c.resolut, hop = c.window;
+    if (n == 0) return GOMEL_ERR_EMPTY;
+    if (num_freqs <= 0) return GOMEL_ERR_BAD_CONFIG;
+    const size_t P = gomel_pad_len(n, hop);
+    if (P < (size_t)N) return GOMEL_ERR_TOO_SHORT;
+    const int nf = std::min(num_freqs, N / 2);                     // shrink keeps j < omels, at most all N/2 pairs
+    const size_t pairs = gomel_phase_pairs(&c, num_freqs, n), F = pairs / (size_t)nf;
+    if (cap_pairs < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    double *d_wave = nullptr, *d_out = nullptr;
+    int rc = GOMEL_OK;
+    if (hipMalloc((void**)&d_wave, P * 8) != hipSuccess || hipMalloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
+                hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
+    if (!rc) {
+        if (N == 4096) hipLaunchKernelGGL(k_phase_stft<4096>, dim3((unsigned)F), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt);
+        else if (N == 2048) hipLaunchKernelGGL(k_phase_stft<2048>, dim3((unsigned)((F + 1) / 2)), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt);
+        else hipLaunchKernelGGL(k_phase_stft<1024>, dim3((unsigned)((F + 3) / 4)), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt);
+        if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    }
+    if (d_wave) hipFree(d_wave);
+    if (d_out) hipFree(d_out);
+    if (!rc && n_pairs) *n_pairs = pairs;
+    return rc;
+}
+
+int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out, size_t out_cap,
+                     size_t* out_len) {
+    if (!h || !pairs || !out) return GOMEL_ERR_NULL;
+    const gomel_config& c = h->cfg;
+    const int N = c.resolut, hop = c.window;
+    if (n_pairs == 0) return GOMEL_ERR_EMPTY;
+    if (num_freqs <= 0 || num_freqs > N / 2) return GOMEL_ERR_BAD_CONFIG;
+    if (n_pairs % (size_t)num_freqs) return GOMEL_ERR_BAD_LENGTH;
+    const size_t F = n_pairs / (size_t)num_freqs, L = (size_t)N + (F - 1) * (size_t)hop;
+    if (out_cap < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    // half the maximum of the window-square sum (phase/phase.go:117-123): data-independent, same accumulation order as the kernel
+    double mx = 0.0;
+    {
+        std::vector<double> ws(L, 0.0);
+        for (size_t i = 0; i < F; i++)
+            for (int j = 0; j < N; j++) ws[i * hop + j] += h->window[j] * h->window[j];
+        for (double v : ws) mx = std::max(mx, v);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(hipSetDevice(h->device));
+    double *d_in = nullptr, *d_yw = nullptr, *d_out = nullptr;
+    int rc = GOMEL_OK;
+    if (hipMalloc((void**)&d_in, n_pairs * 16) != hipSuccess || hipMalloc((void**)&d_yw, F * (size_t)N * 8) != hipSuccess ||
+        hipMalloc((void**)&d_out, L * 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    if (!rc && hipMemcpyAsync(d_in, pairs, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc) {
+        if (N == 4096) hipLaunchKernelGGL(k_phase_istft<4096>, dim3((unsigned)F), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
+        else if (N == 2048) hipLaunchKernelGGL(k_phase_istft<2048>, dim3((unsigned)((F + 1) / 2)), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
+        else hipLaunchKernelGGL(k_phase_istft<1024>, dim3((unsigned)((F + 3) / 4)), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
+        const unsigned g = (unsigned)std::min<size_t>((L + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_phase_ola, dim3(g), dim3(256), 0, h->stream, d_yw, d_out, (int64_t)L, (int)F, N, hop, h->dt.windowd, mx * 0.5, volume_boost);
+        if (hipMemcpyAsync(out, d_out, L * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
+        }
+    }
+    if (d_in) hipFree(d_in);
+    if (d_yw) hipFree(d_yw);
+    if (d_out) hipFree(d_out);
+    if (!rc && out_len) *out_len = L;
+    return rc;
+}
+
 }  // extern "C"

@@ -126,6 +126,18 @@ size_t gomel_to_mel_pairs(const gomel_config* cfg, size_t n_samples);
 int gomel_to_mel(gomel_handle* h, const double* wave, size_t n_samples, double* out_pairs, size_t cap_pairs,
                  size_t* n_pairs);
 
+/* Package phase (the reference's phase-preserving codec, phase/phase.go) on the same handle: the handle supplies Window, Resolut
+ * and the Hann table; NumMels / MelFmax are not used.  NumFreqs and VolumeBoost are the fields of `type Phase` (phase.go:8-18).
+ *   gomel_to_phase   = (*Phase).ToPhase, phase/phase.go:41-72: pad + STFT + (Im S[j+1], Re S[N-1-j]) + shrink to NumFreqs.
+ *   gomel_from_phase = (*Phase).FromPhase, phase/phase.go:137-155: grow + undospectrum + ISTFT with window-sum
+ *                      normalisation (phase.go:96-134) + VolumeBoost.  fp64 throughout. */
+size_t gomel_phase_pairs(const gomel_config* cfg, int32_t num_freqs, size_t n_samples);
+size_t gomel_phase_out_len(const gomel_config* cfg, int32_t num_freqs, size_t n_pairs);
+int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n_samples, double* out_pairs, size_t cap_pairs,
+                   size_t* n_pairs);
+int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out,
+                     size_t out_cap, size_t* out_len);
+
 /* pad / isPadded, mel/impl.go:429-479 (ToWavPng's trim decision, mel/mel.go:228). */
 size_t gomel_pad_len(size_t n, int32_t window);
 int gomel_is_padded(size_t original_len, size_t padded_len, int32_t window);

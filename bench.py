@@ -98,9 +98,10 @@ def host_buffer_rate(engine, fields, n_utt, frames, rank):
     pageable buffers).  Reported next to the HBM-resident figure, never as `value`."""
     mels = make_inputs(fields, n_utt, frames, rank)
     seeds = [1000 + rank * n_utt + u for u in range(n_utt)]
-    engine.from_mel_batch(mels[:2], None, seeds[:2])            # warm
+    outs = [np.zeros(engine.out_len(len(m))) for m in mels]     # caller-owned, already touched (what a Go caller's slices are)
+    engine.from_mel_batch(mels[:2], None, seeds[:2], outs[:2])  # warm
     t = time.perf_counter()
-    engine.from_mel_batch(mels, None, seeds)
+    engine.from_mel_batch(mels, None, seeds, outs)
     return n_utt * frames / (time.perf_counter() - t)
 
 

@@ -33,7 +33,8 @@ static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
 struct gomel_handle {
     gomel_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // compute (and H2D)
+    hipStream_t copy_stream = nullptr;  // D2H of finished chunks, overlapped with the next chunk's compute
     std::mutex mu;
     int path_mode = 0;
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
@@ -184,14 +185,28 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         rc = build_mel_tables(*cfg, h->undo, h->dom, &h->dom_status);
         if (rc) { delete h; return rc; }
     }
-    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (h->stream) hipStreamDestroy(h->stream);
         delete h; return GOMEL_ERR_HIP;
     }
     rc = upload_tables(h);
-    if (rc) { hipStreamDestroy(h->stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
+    if (rc) { hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
     *out = h;
     return GOMEL_OK;
 }
+
+// Pins a caller-owned host buffer for the duration of a copy (hipHostRegister: ~8 ms per GiB, then PCIe runs at full rate;
+// a buffer the driver has never seen copies at a tenth of that).  Falls back to a plain pageable copy when registration is
+// refused (already registered by the caller, not page-backed, ...).
+struct PinnedScope {
+    std::vector<void*> regs;
+    void pin(const void* p, size_t bytes) {
+        if (bytes >= (1u << 20) && hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) regs.push_back(const_cast<void*>(p));
+        else (void)hipGetLastError();
+    }
+    ~PinnedScope() { for (void* p : regs) (void)hipHostUnregister(p); }
+};
 
 // ----------------------------------------------------------------------------------------------- batch
 struct gomel_batch {
@@ -476,6 +491,7 @@ int gomel_destroy(gomel_handle* h) {
     if (!h) return GOMEL_OK;
     hipSetDevice(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
+    if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     if (h->d_blob) hipFree(h->d_blob);
     delete h;
     return GOMEL_OK;
@@ -573,11 +589,9 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
     return GOMEL_OK;
 }
 
-int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
-    if (!b || !mel) return GOMEL_ERR_NULL;
+// H2D of log-mel and x0 on the compute stream (asynchronous when `pins` already covers the host buffers).
+static int batch_upload_impl(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds, bool pin_here, bool wait) {
     gomel_handle* h = b->h;
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
     b->any_x0 = false;
     for (size_t u = 0; u < b->n_utt; u++) {
         if (!mel[u]) return GOMEL_ERR_NULL;
@@ -586,6 +600,12 @@ int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* c
         b->any_x0 |= b->utts[u].has_x0 != 0;
     }
     if (b->any_x0 && !b->d_x0) HIPCHK(hipMalloc((void**)&b->d_x0, (size_t)b->total_len * 8));
+    PinnedScope pins;
+    if (pin_here)
+        for (size_t u = 0; u < b->n_utt; u++) {
+            pins.pin(mel[u], b->n_pairs[u] * 16);
+            if (b->utts[u].has_x0) pins.pin(x0[u], (size_t)b->utts[u].len * 8);
+        }
     int64_t poff = 0;
     for (size_t u = 0; u < b->n_utt; u++) {
         HIPCHK(hipMemcpyAsync(b->d_mel + poff * 2, mel[u], b->n_pairs[u] * 16, hipMemcpyHostToDevice, h->stream));
@@ -594,9 +614,16 @@ int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* c
             HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (wait || pin_here) HIPCHK(hipStreamSynchronize(h->stream));
     b->uploaded = true;
     return GOMEL_OK;
+}
+
+int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
+    if (!b || !mel) return GOMEL_ERR_NULL;
+    std::lock_guard<std::mutex> lk(b->h->mu);
+    HIPCHK(hipSetDevice(b->h->device));
+    return batch_upload_impl(b, mel, x0, seeds, true, true);
 }
 
 int gomel_batch_run(gomel_batch* b) {
@@ -630,6 +657,8 @@ int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_c
         if (!out[u]) return GOMEL_ERR_NULL;
         if (out_cap && out_cap[u] < (size_t)b->utts[u].len) return GOMEL_ERR_BUFFER_TOO_SMALL;
     }
+    PinnedScope pins;
+    for (size_t u = 0; u < b->n_utt; u++) pins.pin(out[u], (size_t)b->utts[u].len * 8);
     for (size_t u = 0; u < b->n_utt; u++)
         HIPCHK(hipMemcpyAsync(out[u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -645,21 +674,70 @@ int gomel_batch_destroy(gomel_batch* b) {
     return GOMEL_OK;
 }
 
+// Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances: chunk i computes on the
+// compute stream while chunk i-1's waveforms go back over PCIe on the copy stream (all caller buffers pinned for the call).
 int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
                          const uint64_t* seeds, double* const* out, const size_t* out_cap) {
     if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
-    if (out_cap)
-        for (size_t u = 0; u < n_utt; u++) {
-            size_t L = gomel_out_len(&h->cfg, n_pairs[u]);
-            if (L && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    if (n_utt == 0) return GOMEL_ERR_EMPTY;
+    const int K = h->cfg.num_mels;
+    int64_t total_frames = 0;
+    for (size_t u = 0; u < n_utt; u++) {
+        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
+        if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
+        if (!mel[u] || !out[u]) return GOMEL_ERR_NULL;
+        const size_t L = gomel_out_len(&h->cfg, n_pairs[u]);
+        if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+        total_frames += (int64_t)(n_pairs[u] / (size_t)K);
+    }
+    // chunk plan: at least ~16k frames per chunk (enough to fill the chip), at most 8 chunks
+    const int64_t kMinChunkFrames = 16384;
+    int n_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(1, total_frames / kMinChunkFrames));
+    n_chunks = (int)std::min<size_t>((size_t)n_chunks, n_utt);
+    std::vector<size_t> bounds(1, 0);
+    {
+        int64_t acc = 0;
+        size_t u = 0;
+        for (int c = 1; c < n_chunks; c++) {
+            const int64_t target = total_frames * c / n_chunks;
+            while (u < n_utt && acc < target) acc += (int64_t)(n_pairs[u++] / (size_t)K);
+            bounds.push_back(std::max(u, bounds.back() + 1));
         }
-    gomel_batch* b = nullptr;
-    int rc = gomel_batch_create(h, n_utt, n_pairs, &b);
-    if (rc) return rc;
-    rc = gomel_batch_upload(b, mel, x0, seeds);
-    if (!rc) rc = gomel_batch_run(b);
-    if (!rc) rc = gomel_batch_download(b, out, out_cap);
-    gomel_batch_destroy(b);
+        bounds.push_back(n_utt);
+        for (size_t i = 1; i < bounds.size(); i++) if (bounds[i] <= bounds[i - 1] || bounds[i] > n_utt) { bounds.assign({0, n_utt}); break; }
+        n_chunks = (int)bounds.size() - 1;
+    }
+    std::vector<gomel_batch*> chunks((size_t)n_chunks, nullptr);
+    int rc = GOMEL_OK;
+    for (int c = 0; c < n_chunks && !rc; c++) rc = gomel_batch_create(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], &chunks[c]);
+    if (!rc) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (hipSetDevice(h->device) != hipSuccess) rc = GOMEL_ERR_HIP;
+        PinnedScope pins;
+        std::vector<hipEvent_t> done((size_t)n_chunks, nullptr);
+        for (size_t u = 0; u < n_utt && !rc; u++) {
+            pins.pin(mel[u], n_pairs[u] * 16);
+            pins.pin(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
+            if (x0 && x0[u]) pins.pin(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
+        }
+        for (int c = 0; c < n_chunks && !rc; c++) {
+            gomel_batch* b = chunks[c];
+            const size_t u0 = bounds[c];
+            std::vector<uint64_t> gseeds;                      // default seed = GLOBAL utterance index, whatever the chunking
+            if (!seeds) { gseeds.resize(b->n_utt); for (size_t u = 0; u < b->n_utt; u++) gseeds[u] = (uint64_t)(u0 + u); }
+            rc = batch_upload_impl(b, mel + u0, x0 ? x0 + u0 : nullptr, seeds ? seeds + u0 : gseeds.data(), false, false);
+            if (!rc) rc = batch_run_impl(b, nullptr);
+            if (!rc && (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], h->stream) != hipSuccess ||
+                        hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+            for (size_t u = 0; u < b->n_utt && !rc; u++)
+                if (hipMemcpyAsync(out[u0 + u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess)
+                    rc = GOMEL_ERR_HIP;
+        }
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
+        if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
+        for (hipEvent_t e : done) if (e) hipEventDestroy(e);
+    }
+    for (gomel_batch* b : chunks) if (b) gomel_batch_destroy(b);
     return rc;
 }
 

@@ -98,14 +98,34 @@ class Engine:
                                out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_from_mel")
         return out[:got.value]
 
-    def from_mel_batch(self, mels, x0s=None, seeds=None):
-        b = Batch(self, [len(m) for m in mels])
-        try:
-            b.upload(mels, x0s, seeds)
-            b.run()
-            return b.download()
-        finally:
-            b.close()
+    def from_mel_batch(self, mels, x0s=None, seeds=None, outs=None):
+        """gomel_from_mel_batch: host buffers in, host buffers out (chunked, copy/compute overlapped inside the library).
+        `outs` may be preallocated float64 arrays (caller-owned buffers); otherwise fresh arrays are returned."""
+        ms = [_as_pairs(m) for m in mels]
+        n = len(ms)
+        if n == 0:
+            return []
+        lens = [self.out_len(len(m)) for m in ms]
+        if outs is None:
+            outs = [np.empty(max(L, 1), dtype=np.float64) for L in lens]
+        elif len(outs) != n or any(o.dtype != np.float64 or o.ndim != 1 or len(o) < L or not o.flags.c_contiguous for o, L in zip(outs, lens)):
+            raise ValueError("outs must be C-contiguous float64 arrays of at least the output lengths")
+        xs = None
+        if x0s is not None:
+            xs = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in x0s]
+            for x, L in zip(xs, lens):
+                if x is not None and x.shape != (L,):
+                    raise ValueError("x0 length mismatch")
+        dpp = ctypes.POINTER(c_double_p)
+        mp = (c_double_p * n)(*[m.ctypes.data_as(c_double_p) for m in ms])
+        op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
+        xp = None if xs is None else (c_double_p * n)(*[None if x is None else x.ctypes.data_as(c_double_p) for x in xs])
+        sp = None if seeds is None else (ctypes.c_uint64 * n)(*[int(s) & (2 ** 64 - 1) for s in seeds])
+        npairs = (ctypes.c_size_t * n)(*[len(m) for m in ms])
+        caps = (ctypes.c_size_t * n)(*[len(o) for o in outs])
+        check(_lib.lib().gomel_from_mel_batch(self._h, n, ctypes.cast(mp, dpp), npairs, None if xp is None else ctypes.cast(xp, dpp), sp,
+                                              ctypes.cast(op, dpp), caps), "gomel_from_mel_batch")
+        return [o[:L] for o, L in zip(outs, lens)]
 
     def target_magnitudes(self, mel_pairs):
         m = _as_pairs(mel_pairs)
@@ -190,9 +210,14 @@ class Batch:
     def sync(self):
         check(_lib.lib().gomel_batch_sync(self._b), "gomel_batch_sync")
 
-    def download(self):
+    def download(self, outs=None):
+        """Copy the waveforms back.  `outs` may be a list of preallocated float64 arrays (caller-owned buffers, as the Go
+        side would pass); otherwise fresh arrays are returned."""
         n = len(self.n_pairs)
-        outs = [np.empty(L, dtype=np.float64) for L in self.lens]
+        if outs is None:
+            outs = [np.empty(L, dtype=np.float64) for L in self.lens]
+        elif len(outs) != n or any(o.dtype != np.float64 or o.shape != (L,) or not o.flags.c_contiguous for o, L in zip(outs, self.lens)):
+            raise ValueError("outs must be C-contiguous float64 arrays of the planned lengths")
         op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
         caps = (ctypes.c_size_t * n)(*self.lens)
         check(_lib.lib().gomel_batch_download(self._b, op, caps), "gomel_batch_download")

@@ -50,6 +50,7 @@ SYMBOLS = {
     "gomel_batch_download": (ctypes.c_int, [_vp, ctypes.POINTER(c_double_p), c_size_p]),
     "gomel_batch_destroy": (ctypes.c_int, [_vp]),
     "gomel_set_path": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "gomel_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_to_mel_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
     "gomel_to_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
     "gomel_phase_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_int32, ctypes.c_size_t]),

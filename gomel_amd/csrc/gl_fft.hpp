@@ -563,4 +563,56 @@ template <class G> GL_DEV void spectral_apply(v2f (&v)[16], int t, const MagRegs
     lane0_unpermute<G>(v, is0, dc);
 }
 
+// ---------------------------------------------------------------------------------------------- fp64 spectral step ("precise" mode)
+// Same arithmetic as the fp32 forms above, in double: used by the generic kernels when the handle's precision is 64 bits.
+struct MagRegsD {
+    double ma[8], mb[8];
+    double m0, mn;
+};
+template <class G> GL_DEV void load_mags(MagRegsD& m, int t, const double* __restrict__ mag_row, const double* __restrict__ nyq) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        m.ma[e] = mag_row[((e / 4) * G::T + t) * 4 + (e % 4)];
+        m.mb[e] = mag_row[(((8 + e) / 4) * G::T + t) * 4 + (e % 4)];
+    }
+    m.m0 = 0.0; m.mn = 0.0;
+    if (t == 0) { m.m0 = m.mb[0]; m.mb[0] = m.ma[0]; m.mn = nyq[0]; }
+}
+template <class G> GL_DEV void load_wn(v2d (&w)[8], int t, const v2d* __restrict__ wn) {
+#pragma unroll
+    for (int s = 0; s < 8; s++) w[s] = wn[slot_bin<G>(t, s)];
+}
+GL_DEV v2d unit_phase_d(v2d x) {   // cmplx.Phase(0) = 0 -> (1, 0); scaled so that the squared modulus cannot under/overflow
+    const double big = fmax(fabs(x.x), fabs(x.y));
+    if (!(big > 0.0)) return v2d{1.0, 0.0};
+    const double sc = 1.0 / big;
+    const v2d y = v2d{x.x * sc, x.y * sc};
+    const double r = 1.0 / sqrt(y.x * y.x + y.y * y.y);
+    return v2d{y.x * r, y.y * r};
+}
+GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
+    v2d bc = v2d{b.x, -b.y};
+    v2d p = a + bc, d = a - bc;
+    v2d q = cmul(w, rot_mi(d));
+    v2d xk = p + q, xc = p - q;
+    v2d u = unit_phase_d(xk) * ma, vv = unit_phase_d(xc) * mb;
+    v2d e = u + vv, o = cmulc(u - vv, w), io = rot_pi(o);
+    a = e + io;
+    v2d t = e - io;
+    b = v2d{t.x, -t.y};
+}
+template <class G> GL_DEV void spectral_apply(v2d (&v)[16], int t, const MagRegsD& m, const v2d (&w)[8]) {
+    const bool is0 = (t == 0);
+    v2d dc = v[0];
+    lane0_permute<G>(v, is0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) clamp_pair_d(v[s], v[15 - s], w[s], m.ma[s], m.mb[s]);
+    if (is0) {
+        const double x0 = dc.x + dc.y, xn = dc.x - dc.y;
+        const double y0 = x0 < 0.0 ? -m.m0 : m.m0, yn = xn < 0.0 ? -m.mn : m.mn;
+        dc = v2d{y0 + yn, y0 - yn};
+    }
+    lane0_unpermute<G>(v, is0, dc);
+}
+
 }  // namespace glfft

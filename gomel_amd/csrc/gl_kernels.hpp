@@ -48,9 +48,9 @@ GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
 // =============================================================================================== K1: log-mel -> target magnitudes
 // One block per frame.  mag[f][slot(k)] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from
 // channel 1 at bin N/2-1 (the only survivor of channel 1).  fp64 arithmetic, fp32 result.
-template <int N>
+template <int N, class MagT>
 __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
-                                                    float* __restrict__ mag, float* __restrict__ nyq, int K,
+                                                    MagT* __restrict__ mag, MagT* __restrict__ nyq, int K,
                                                     double tune_add, double tune_mul, double inv_n) {
     constexpr int H = N / 2;
     extern __shared__ double e_sh[];  // [2][K]
@@ -64,20 +64,21 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
         const BinRow r = undo[i];
         double v0 = (apply_row(r, e_sh) - tune_add) / tune_mul;
-        mag[f * H + mag_slot_index<Geo<N>>(i)] = (float)(fabs(v0) * inv_n);   // lane-slot order, see gl_fft.hpp
+        mag[f * H + mag_slot_index<Geo<N>>(i)] = (MagT)(fabs(v0) * inv_n);   // lane-slot order, see gl_fft.hpp
         if (i == H - 1) {
             double v1 = (apply_row(r, e_sh + K) - tune_add) / tune_mul;
-            nyq[f] = (float)(fabs(v1) * inv_n);
+            nyq[f] = (MagT)(fabs(v1) * inv_n);
         }
     }
 }
 
-static void launch_mel_to_mag(int N, unsigned frames, size_t shmem, hipStream_t s, const double* mel, const BinRow* undo, float* mag, float* nyq,
+template <class MagT>
+static void launch_mel_to_mag(int N, unsigned frames, size_t shmem, hipStream_t s, const double* mel, const BinRow* undo, MagT* mag, MagT* nyq,
                               int K, double tune_add, double tune_mul) {
     const double inv_n = 1.0 / (double)N;
-    if (N == 4096) hipLaunchKernelGGL(k_mel_to_mag<4096>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
-    else if (N == 2048) hipLaunchKernelGGL(k_mel_to_mag<2048>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
-    else hipLaunchKernelGGL(k_mel_to_mag<1024>, dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    if (N == 4096) hipLaunchKernelGGL((k_mel_to_mag<4096, MagT>), dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    else if (N == 2048) hipLaunchKernelGGL((k_mel_to_mag<2048, MagT>), dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    else hipLaunchKernelGGL((k_mel_to_mag<1024, MagT>), dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
 }
 
 // =============================================================================================== K3: initial signal
@@ -146,15 +147,50 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
     }
 }
 
+
+// fp64 ("precise") version of the generic frames kernel: same structure, double LDS / twiddles / window / magnitudes.
+template <int N>
+__global__ __launch_bounds__(128) void k_gl_frames_d(const double* __restrict__ x, const int64_t* __restrict__ frame_xoff,
+                                                     const double* __restrict__ mag, const double* __restrict__ nyq,
+                                                     double* __restrict__ yw, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    auto sync = [] { __syncthreads(); };
+    const v2d* xs = reinterpret_cast<const v2d*>(x + frame_xoff[frame]);
+    const v2d* w2 = reinterpret_cast<const v2d*>(tb.windowd);
+    v2d v[16], wn[8];
+    MagRegsD mr;
+    load_mags<G>(mr, t, mag + frame * G::C, nyq + frame);
+    load_wn<G>(wn, t, tb.wnd);
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j] * w2[t + G::T * j];
+    fft_forward<G>(v, my, t, tw, sync);
+    spectral_apply<G>(v, t, mr, wn);
+    fft_inverse<G>(v, my, t, tw, sync);
+    if (live) {
+        v2d* ys = reinterpret_cast<v2d*>(yw + frame * N);
+#pragma unroll
+        for (int j = 0; j < 16; j++) ys[t + G::T * j] = v[j] * w2[t + G::T * j];
+    }
+}
+
 // x'[n] = sum over the frames covering n of yw[k][n - k*hop], in frame order (mel/mel.go:115-125).
-__global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, const float* __restrict__ yw, float* __restrict__ xn,
+template <class S>
+__global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, const S* __restrict__ yw, S* __restrict__ xn,
                                              int N, int hop) {
     const UttDesc u = utts[blockIdx.y];
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
         int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
         int64_t k1 = n / hop;
         if (k1 > u.frames - 1) k1 = u.frames - 1;
-        float acc = 0.f;
+        S acc = 0;
         for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
         xn[u.xoff + n] = acc;
     }

@@ -37,6 +37,7 @@ struct gomel_handle {
     hipStream_t copy_stream = nullptr;  // D2H of finished chunks, overlapped with the next chunk's compute
     std::mutex mu;
     int path_mode = 0;
+    int precision = 32;           // 32: fp32 kernels (default); 64: fp64 generic kernels ("precise" mode)
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
     std::vector<double> window;   // [N]
     std::vector<BinRow> undo;     // [N/2]
@@ -225,6 +226,11 @@ struct gomel_batch {
     float* d_nyq = nullptr;    // [total_frames]
     float* d_x[2] = {nullptr, nullptr};  // ping-pong signal
     float* d_yw = nullptr;     // generic path: [total_frames][N]
+    int precise = 0;           // fp64 mode: the four buffers below replace d_mag / d_nyq / d_x / d_yw
+    double* d_magd = nullptr;
+    double* d_nyqd = nullptr;
+    double* d_xd[2] = {nullptr, nullptr};
+    double* d_ywd = nullptr;
     int64_t* d_frame_xoff = nullptr;
     UttDesc* d_utts = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -240,7 +246,7 @@ static void batch_free(gomel_batch* b) {
     if (!b) return;
     hipSetDevice(b->h->device);
     void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
-                    b->d_segs, b->d_tail[0], b->d_tail[1]};
+                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
@@ -328,7 +334,25 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_out);
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
-        launch_mel_to_mag(N, (unsigned)b->total_frames, (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
+        if (b->precise) {   // fp64 generic kernels end to end
+            launch_mel_to_mag<double>(N, (unsigned)b->total_frames, (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
+            hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_xd[0]);
+            if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
+            int curd = 0;
+            const int64_t blocks = (b->total_frames + (128 / (N / 32)) - 1) / (128 / (N / 32));
+            for (int it = 0; it < I; it++) {
+                if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
+                if (N == 4096) hipLaunchKernelGGL(k_gl_frames_d<4096>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt);
+                else if (N == 2048) hipLaunchKernelGGL(k_gl_frames_d<2048>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt);
+                else hipLaunchKernelGGL(k_gl_frames_d<1024>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt);
+                if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
+                hipLaunchKernelGGL(k_ola<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
+                curd ^= 1;
+            }
+            if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
+            HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
+        } else {
+        launch_mel_to_mag<float>(N, (unsigned)b->total_frames, (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
         hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
@@ -341,13 +365,14 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             else if (N == 2048) launch_frames<2048>(b, b->d_x[cur]);
             else launch_frames<1024>(b, b->d_x[cur]);
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
-            if (!b->fast) hipLaunchKernelGGL(k_ola, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
+            if (!b->fast) hipLaunchKernelGGL(k_ola<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
             cur ^= 1;
         }
         if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
         const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
         hipLaunchKernelGGL(k_finalize, dim3(gf), dim3(256), 0, s, b->d_x[cur], b->d_out, b->total_len);
         if (b->fast) hipLaunchKernelGGL(k_add_tails, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], b->d_out, N - c.window, c.window);
+        }
     }
     HIPCHK(hipGetLastError());
     if (tm) {
@@ -487,6 +512,13 @@ int gomel_set_path(gomel_handle* h, int mode) {
     return GOMEL_OK;
 }
 
+int gomel_set_precision(gomel_handle* h, int bits) {
+    if (!h) return GOMEL_ERR_NULL;
+    if (bits != 32 && bits != 64) return GOMEL_ERR_BAD_CONFIG;
+    h->precision = bits;
+    return GOMEL_OK;
+}
+
 int gomel_destroy(gomel_handle* h) {
     if (!h) return GOMEL_OK;
     hipSetDevice(h->device);
@@ -553,14 +585,22 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
     }
     // Path choice: the fused kernel walks >= 3 consecutive frames per stream, which only pays once there are enough frames
     // to fill the chip; one short utterance (<= 512 frames, measured crossover) is faster with every frame in parallel.
-    b->fast = (h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames > 512)) ? 1 : 0;
+    b->precise = h->precision == 64 ? 1 : 0;
+    b->fast = (!b->precise && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames > 512)) ? 1 : 0;
     const int I = c.griffin_lim_iterations;
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
     alloc((void**)&b->d_mel, (size_t)b->total_pairs * 16);
     alloc((void**)&b->d_out, (size_t)b->total_len * 8);
     alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
-    if (I > 0) {
+    if (I > 0 && b->precise) {
+        alloc((void**)&b->d_magd, (size_t)b->total_frames * (N / 2) * 8);
+        alloc((void**)&b->d_nyqd, (size_t)b->total_frames * 8);
+        alloc((void**)&b->d_xd[0], (size_t)b->total_len * 8);
+        alloc((void**)&b->d_xd[1], (size_t)b->total_len * 8);
+        alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8);
+        alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+    } else if (I > 0) {
         alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);
         alloc((void**)&b->d_nyq, (size_t)b->total_frames * 4);
         alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
@@ -773,7 +813,7 @@ int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, 
         hipMalloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc && hipMemcpyAsync(d_mel, mel, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        launch_mel_to_mag(N, (unsigned)F, (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
+        launch_mel_to_mag<float>(N, (unsigned)F, (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
         std::vector<float> mg(F * H), ny(F);
         if (hipMemcpyAsync(mg.data(), d_mag, F * H * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipMemcpyAsync(ny.data(), d_nyq, F * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||

@@ -73,6 +73,9 @@ class Engine:
     def set_path(self, mode):
         check(_lib.lib().gomel_set_path(self._h, int(mode)), "gomel_set_path")
 
+    def set_precision(self, bits):
+        check(_lib.lib().gomel_set_precision(self._h, int(bits)), "gomel_set_precision")
+
     def device_name(self):
         buf = ctypes.create_string_buffer(256)
         check(_lib.lib().gomel_device_name(self._h, buf, 256), "gomel_device_name")

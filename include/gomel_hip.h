@@ -120,6 +120,9 @@ int gomel_batch_destroy(gomel_batch* b);
 /* 0 = let the library choose (fused kernel when the hop allows it and the batch has more than 512 frames);
  * 1 = force the generic kernels; 2 = require the fused kernel (error if the hop is not SH*Resolut/16, SH in 1,2,4,5,8) */
 int gomel_set_path(gomel_handle* h, int mode);
+/* Arithmetic of the Griffin-Lim iteration for batches created afterwards: 32 (default: fp32 kernels, the benchmarked path) or
+ * 64 ("precise": the generic kernels in fp64 end to end, ~1e-12 from the fp64 reference arithmetic, several times slower). */
+int gomel_set_precision(gomel_handle* h, int bits);
 
 /* (*Mel).ToMel, mel/mel.go:46-74 = pad + gossp STFT + |S[j]|,|S[N-1-j]| + domel + ln(max(v,1e-5)). */
 size_t gomel_to_mel_pairs(const gomel_config* cfg, size_t n_samples);

@@ -270,3 +270,19 @@ def test_automatic_path_choice(oracle):
         b.close()
         cfg = ocfg(oracle, "T", 2)
         assert rms(out - oracle.from_mel(cfg, mels[0].copy(), oracle.x0_splitmix(0, len(out)))) < RMS_TOL
+
+
+@pytest.mark.parametrize("geom,frames,iters", [("T", 9, 60), ("S", 24, 60), ("D", 12, 20), ("T", 3, 2)])
+def test_precise_mode_is_the_fp64_algorithm(oracle, geom, frames, iters):
+    """gomel_set_precision(64): the generic kernels in fp64 end to end.  Against the fp64 oracle this is agreement between two
+    implementations of the same arithmetic (different FFT factorisation, different summation order): ~1e-13."""
+    m = make_mel(geom, iters)
+    m.engine().set_precision(64)
+    cfg = ocfg(oracle, geom, iters)
+    mel = oracle.random_logmel(frames, cfg.NumMels, seed=31 + frames)
+    x0 = oracle.x0_splitmix(11, oracle.out_len(cfg, len(mel)))
+    want = oracle.from_mel(cfg, mel.copy(), x0)
+    got = m.FromMel(mel.copy(), x0=x0)
+    assert rms(got - want) < 1e-10 * max(1.0, rms(want)), rms(got - want)
+    m.engine().set_precision(32)
+    assert 1e-10 < rms(m.FromMel(mel.copy(), x0=x0) - want) < RMS_TOL      # back to the fp32 kernels

@@ -257,6 +257,7 @@ class Mel:
         # not in the reference: which GPU, and which Hann definition (see DESIGN.md "window")
         self.Device = -1
         self.HannPeriodic = False
+        self.Precision = 32           # 32: fp32 kernels (default); 64: fp64 "precise" mode (gomel_set_precision)
         self._engines = {}
 
     def _config(self):
@@ -276,6 +277,10 @@ class Mel:
         if e is None:
             e = Engine(c)
             self._engines = {key: e}  # one live handle per Mel object
+            e._precision = 32
+        if e._precision != int(self.Precision):
+            e.set_precision(int(self.Precision))
+            e._precision = int(self.Precision)
         return e
 
     # mel/mel.go:46-74

@@ -164,3 +164,46 @@ def test_full_size_config3_properties(oracle):
     for u in (3, 200):
         want = oracle.from_mel(cfg, mels[u].copy(), oracle.x0_splitmix(seeds[u], L))
         assert rms(out1[u] - want) < RMS_TOL, (u, rms(out1[u] - want))
+
+
+def test_concurrent_callers_share_and_separate_handles(oracle):
+    """The reference is plain Go and callable from many goroutines; the handle serialises calls on itself with a mutex and sets
+    the device on every entry.  Eight host threads hammer one shared handle and one private handle each."""
+    import threading
+    m_shared = mel_obj(FIELDS["tts_n1024"], GriffinLimIterations=3)
+    shared = m_shared.engine()
+    cfg = oracle.MelConfig(GriffinLimIterations=3, **FIELDS["tts_n1024"])
+    mels = [oracle.random_logmel(5 + i, 80, seed=i) for i in range(8)]
+    wants = [oracle.from_mel(cfg, mm.copy(), oracle.x0_splitmix(i, oracle.out_len(cfg, len(mm)))) for i, mm in enumerate(mels)]
+    errors = []
+
+    def work(i):
+        try:
+            own = mel_obj(FIELDS["tts_n1024"], GriffinLimIterations=3).engine()
+            for _ in range(6):
+                for e in (shared, own):
+                    got = e.from_mel(mels[i], seed=i)
+                    if rms(got - wants[i]) > RMS_TOL:
+                        errors.append((i, rms(got - wants[i])))
+            own.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_precision_field_on_mel(oracle):
+    m = mel_obj(FIELDS["tts_n1024"], GriffinLimIterations=10)
+    cfg = oracle.MelConfig(GriffinLimIterations=10, **FIELDS["tts_n1024"])
+    mel = oracle.random_logmel(12, 80, seed=3)
+    x0 = oracle.x0_splitmix(2, oracle.out_len(cfg, len(mel)))
+    want = oracle.from_mel(cfg, mel.copy(), x0)
+    m.Precision = 64
+    assert rms(m.FromMel(mel.copy(), x0=x0) - want) < 1e-10
+    m.Precision = 32
+    assert 1e-10 < rms(m.FromMel(mel.copy(), x0=x0) - want) < RMS_TOL

@@ -1,0 +1,28 @@
+/* Compiled as C99 by tests/test_abi.py: the header must be plain C (cgo compiles it as C), and the host-only entry points
+ * must work from a C caller without a GPU. */
+#include <stdio.h>
+#include <string.h>
+
+#include "gomel_hip.h"
+
+int main(void) {
+    gomel_config c;
+    if (gomel_default_config(&c) != GOMEL_OK) return 1;
+    if (c.num_mels != 160 || c.window != 256 || c.resolut != 2048 || c.griffin_lim_iterations != 2) return 2; /* mel/mel.go:30-41 */
+    c.num_mels = 192; c.window = 1280; c.resolut = 4096;
+    if (gomel_out_len(&c, (size_t)342 * 192) != 440576) return 3;
+    if (gomel_pad_len(441000, 1280) != 441599 || !gomel_is_padded(441000, 441599, 1280)) return 4;       /* mel/impl.go:429-479 */
+    if (gomel_to_mel_pairs(&c, 441000) != (size_t)342 * 192) return 5;
+    if (gomel_phase_pairs(&c, 768, 441000) != (size_t)342 * 768 || gomel_phase_out_len(&c, 768, (size_t)342 * 768) != 440576) return 6;
+    if (strcmp(gomel_strerror(GOMEL_OK), "ok") != 0 || gomel_abi_version() != GOMEL_HIP_ABI_VERSION) return 7;
+    gomel_handle* h = NULL;
+    int rc = gomel_create(&c, &h);
+    if (gomel_device_count() == 0) {
+        if (rc != GOMEL_ERR_NO_DEVICE || h != NULL) return 8;   /* no GPU: refuse, never fall back */
+    } else {
+        if (rc != GOMEL_OK || h == NULL) return 9;
+        gomel_destroy(h);
+    }
+    printf("c abi ok (devices: %d)\n", gomel_device_count());
+    return 0;
+}

@@ -112,3 +112,19 @@ def test_newmel_mirror_fields():
     assert str(gomel_amd.ErrFileNotLoaded()) == "wavNotLoaded"           # mel/mel.go:43
     with pytest.raises(TypeError):
         m.FromMel([[0.0, 0.0]] * 160)                                     # must be an in-place-modifiable float64 array
+
+
+def test_header_is_plain_c_and_links_from_c(L, tmp_path):
+    """cgo compiles include/gomel_hip.h as C: build tests/c_abi_check.c as strict C99 against it, link libgomel_hip.so, run it."""
+    import shutil
+    import subprocess
+    from gomel_amd import _lib
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_abi_check")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe, "-L", libdir, "-lgomel_hip", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "c abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -99,7 +99,7 @@ def host_buffer_rate(engine, fields, n_utt, frames, rank):
     mels = make_inputs(fields, n_utt, frames, rank)
     seeds = [1000 + rank * n_utt + u for u in range(n_utt)]
     outs = [np.zeros(engine.out_len(len(m))) for m in mels]     # caller-owned, already touched (what a Go caller's slices are)
-    engine.from_mel_batch(mels[:2], None, seeds[:2], outs[:2])  # warm
+    engine.from_mel_batch(mels, None, seeds, outs)              # warm: first-use allocation and page registration costs
     t = time.perf_counter()
     engine.from_mel_batch(mels, None, seeds, outs)
     return n_utt * frames / (time.perf_counter() - t)

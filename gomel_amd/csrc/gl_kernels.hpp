@@ -127,7 +127,10 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
     if (!live) frame = n_frames - 1;  // keep the lanes in the barriers; results are dropped
     v2f* my = lds + stream * G::LDS_SLOTS;
     const Twiddles<v2f> tw{tb.tw1, tb.tw2, tb.wn};
-    auto sync = [] { __syncthreads(); };
+    auto sync = [] {   // single-wave streams exchange through LDS in program order: no s_barrier needed (see k_gl_fused)
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
 
     const v2f* xs = reinterpret_cast<const v2f*>(x + frame_xoff[frame]);  // hop and offsets are even: 8-byte aligned
     const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);

@@ -203,10 +203,16 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
 struct PinnedScope {
     std::vector<void*> regs;
     void pin(const void* p, size_t bytes) {
-        if (bytes >= (1u << 20) && hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) regs.push_back(const_cast<void*>(p));
-        else (void)hipGetLastError();
+        if (bytes < (1u << 20)) return;
+        void* q = const_cast<void*>(p);
+        if (std::find(regs.begin(), regs.end(), q) != regs.end()) return;   // the same buffer passed for several utterances
+        if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) regs.push_back(q);
+        (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
     }
-    ~PinnedScope() { for (void* p : regs) (void)hipHostUnregister(p); }
+    ~PinnedScope() {
+        for (void* p : regs) (void)hipHostUnregister(p);
+        (void)hipGetLastError();
+    }
 };
 
 // ----------------------------------------------------------------------------------------------- batch

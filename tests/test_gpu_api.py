@@ -207,3 +207,26 @@ def test_precision_field_on_mel(oracle):
     assert rms(m.FromMel(mel.copy(), x0=x0) - want) < 1e-10
     m.Precision = 32
     assert 1e-10 < rms(m.FromMel(mel.copy(), x0=x0) - want) < RMS_TOL
+
+
+def test_aliased_and_repeated_host_buffers(oracle):
+    """The same host array passed for several utterances, and big (> 1 MiB, i.e. pinned for the call) buffers that alias each
+    other: legal inputs; the library pins caller buffers for the duration of a call and must cope."""
+    import gomel_amd
+    m = mel_obj(FIELDS["towav_n4096"], GriffinLimIterations=1)
+    e = m.engine()
+    mel = oracle.random_logmel(400, 192, seed=1)             # 1.2 MB: above the pinning threshold
+    for call in range(2):
+        outs = e.from_mel_batch([mel] * 6, None, [5] * 6)
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
+        b = gomel_amd.Batch(e, [len(mel)] * 4)
+        b.upload([mel] * 4, None, [5] * 4)
+        b.run()
+        big = np.zeros(4 * len(outs[0]))
+        views = [big[i * len(outs[0]):(i + 1) * len(outs[0])] for i in range(4)]   # four slices of ONE allocation
+        got = b.download(views)
+        b.close()
+        assert all(np.array_equal(g, outs[0]) for g in got)
+    cfg = oracle.MelConfig(GriffinLimIterations=1, **FIELDS["towav_n4096"])
+    want = oracle.from_mel(cfg, mel.copy(), oracle.x0_splitmix(5, len(outs[0])))
+    assert rms(outs[0] - want) < RMS_TOL

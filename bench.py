@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Griffin-Lim frames/s (4096-pt, 60 iters) on MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -14,7 +14,8 @@ collective is the one-off broadcast of the table blob ("mel basis") from rank 0 
 Workloads (BASELINE.json configs): cfg3 = configs[2], 256 x (192 mels x 400 frames) random log-mel, N 4096 / hop 1280,
 60 iterations (the configuration the HBM-roofline figure is quoted on; default).  cfg2 = configs[1], one 10 s utterance
 (342 frames) -- launch-latency bound, reported in the same JSON line as "single_utterance".  cfg4 = configs[3], the
-22.05 kHz TTS geometry (N 1024 / hop 256 / 80 mels).
+22.05 kHz TTS geometry (N 1024 / hop 256 / 80 mels).  cfg5 = configs[4], a fixed 8192-utterance corpus cut into one
+contiguous shard per rank (strong scaling; ~105 GB of HBM at N=1).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -37,7 +38,11 @@ WORKLOADS = {
              dict(NumMels=192, MelFmin=0.0, MelFmax=16000.0, Window=1280, Resolut=4096, GriffinLimIterations=60), 1, 342, 44100),
     "cfg4": ("configs[3]: 256 x (80 mels x 400 frames), 22.05kHz TTS geometry N=1024 hop=256, 60 GL iters",
              dict(NumMels=80, MelFmin=0.0, MelFmax=8000.0, Window=256, Resolut=1024, GriffinLimIterations=60), 256, 400, 22050),
+    # configs[4]: a FIXED corpus of 8192 utterances cut into contiguous shards, one per rank (strong scaling; 8192/N per GPU)
+    "cfg5": ("configs[4]: 8192-utterance corpus (192 mels x 400 frames each) sharded over the ranks, N=4096 hop=1280, 60 GL iters",
+             dict(NumMels=192, MelFmin=0.0, MelFmax=16000.0, Window=1280, Resolut=4096, GriffinLimIterations=60), 8192, 400, 44100),
 }
+STRONG = {"cfg5"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -211,6 +216,9 @@ def main():
             dist.barrier()
 
     desc, fields, n_utt, frames, sr = WORKLOADS[args.workload]
+    strong = args.workload in STRONG
+    if strong:
+        n_utt = n_utt // world            # contiguous shard of the fixed corpus
     if args.utts_per_gpu > 0:
         n_utt = args.utts_per_gpu
 
@@ -256,7 +264,7 @@ def main():
         line = {
             "metric": "Griffin-Lim frames/s (4096-pt, 60 iters)" if N == 4096 else "Griffin-Lim frames/s (%d-pt, %d iters)" % (N, I),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "utterances_per_gpu": n_utt, "frames_per_utterance": frames, "resolut": N, "window_hop": hop,
                        "num_mels": fields["NumMels"], "iterations": I, "parallelism": "utterance-sharded x%d" % world,

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/gomel_hip.h"
@@ -197,22 +199,49 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     return GOMEL_OK;
 }
 
-// Pins a caller-owned host buffer for the duration of a copy (hipHostRegister: ~8 ms per GiB, then PCIe runs at full rate;
-// a buffer the driver has never seen copies at a tenth of that).  Falls back to a plain pageable copy when registration is
-// refused (already registered by the caller, not page-backed, ...).
+// Pins caller-owned host buffers for the duration of a call (hipHostRegister: ~8 ms per GiB, then PCIe runs at full rate; a
+// buffer the driver has never seen copies at a tenth of that).  The runtime does not reference-count registrations, and the
+// same buffer may be passed for several utterances or by several threads / handles at once, so every range pinned by this
+// library goes through one process-wide reference-counted registry.  A refused registration (range overlapping one pinned by
+// somebody else, memory that cannot be locked, ...) simply leaves that buffer pageable.
+struct PinRegistry {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<size_t, int>> live;   // base -> (bytes, users)
+    bool acquire(void* p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it != live.end()) {
+            if (it->second.first < bytes) return false;         // pinned shorter than needed: treat as not pinned
+            it->second.second++;
+            return true;
+        }
+        const bool ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
+        if (ok) live.emplace(p, std::make_pair(bytes, 1));
+        return ok;
+    }
+    void release(void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        if (--it->second.second == 0) {
+            (void)hipHostUnregister(p);
+            (void)hipGetLastError();
+            live.erase(it);
+        }
+    }
+};
+static PinRegistry g_pins;
+
 struct PinnedScope {
-    std::vector<void*> regs;
+    std::vector<void*> held;
     void pin(const void* p, size_t bytes) {
         if (bytes < (1u << 20)) return;
         void* q = const_cast<void*>(p);
-        if (std::find(regs.begin(), regs.end(), q) != regs.end()) return;   // the same buffer passed for several utterances
-        if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) regs.push_back(q);
-        (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
+        if (std::find(held.begin(), held.end(), q) != held.end()) return;   // already held by this call
+        if (g_pins.acquire(q, bytes)) held.push_back(q);
     }
-    ~PinnedScope() {
-        for (void* p : regs) (void)hipHostUnregister(p);
-        (void)hipGetLastError();
-    }
+    ~PinnedScope() { for (void* p : held) g_pins.release(p); }
 };
 
 // ----------------------------------------------------------------------------------------------- batch
@@ -660,7 +689,7 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
             HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, h->stream));
-    if (wait || pin_here) HIPCHK(hipStreamSynchronize(h->stream));
+    if (wait || pin_here) HIPCHK(hipStreamSynchronize(h->stream));   // the local pins must outlive the copies
     b->uploaded = true;
     return GOMEL_OK;
 }

@@ -230,3 +230,31 @@ def test_aliased_and_repeated_host_buffers(oracle):
     cfg = oracle.MelConfig(GriffinLimIterations=1, **FIELDS["towav_n4096"])
     want = oracle.from_mel(cfg, mel.copy(), oracle.x0_splitmix(5, len(outs[0])))
     assert rms(outs[0] - want) < RMS_TOL
+
+
+def test_threads_sharing_one_input_buffer(oracle):
+    """Several threads, each with its own handle, pass the SAME large input array at the same time (pinned per call through a
+    reference-counted registry inside the library)."""
+    import threading
+    mel = oracle.random_logmel(400, 192, seed=2)              # 1.2 MB, above the pinning threshold
+    cfg = oracle.MelConfig(GriffinLimIterations=1, **FIELDS["towav_n4096"])
+    want = oracle.from_mel(cfg, mel.copy(), oracle.x0_splitmix(9, oracle.out_len(cfg, len(mel))))
+    errors = []
+
+    def work(i):
+        try:
+            e = mel_obj(FIELDS["towav_n4096"], GriffinLimIterations=1).engine()
+            for _ in range(5):
+                outs = e.from_mel_batch([mel, mel], None, [9, 9])
+                if rms(outs[0] - want) > RMS_TOL or not np.array_equal(outs[0], outs[1]):
+                    errors.append(i)
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]

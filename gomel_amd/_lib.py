@@ -1,7 +1,9 @@
 """ctypes binding of include/gomel_hip.h.  There is no CPU fallback: if libgomel_hip.so is missing or a call
 fails, this raises."""
 import ctypes
+import importlib.util
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgomel_hip.so")
@@ -81,12 +83,39 @@ class GomelError(RuntimeError):
         super().__init__("%s: %s (status %d)" % (where, msg, status))
 
 
+_hip_runtime = None
+
+
+def _share_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so with the SONAME of the system
+    copy (libamdhip64.so.7) but asks for it by file name: if libgomel_hip.so pulled in /opt/rocm's copy first, a later
+    `import torch` would load a second runtime next to it (torch then reports no GPU, and device pointers / streams are not
+    interchangeable).  Loading torch's copy first, when there is one, makes the import order irrelevant: the library's
+    DT_NEEDED libamdhip64.so.7 then resolves to it.  GOMEL_HIP_RUNTIME=system skips this."""
+    global _hip_runtime
+    if _hip_runtime is not None or "torch" in sys.modules or os.environ.get("GOMEL_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            _hip_runtime = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            _hip_runtime = None
+
+
 def lib():
     """Load libgomel_hip.so (built in-tree by gomel_amd.build).  Raises if it is absent: no fallback."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("gomel_amd: %s not found -- run `python -m gomel_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        _share_hip_runtime()
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the library lacks a declared symbol

@@ -24,6 +24,12 @@ static thread_local int g_last_hip = 0;
         if (e_ != hipSuccess) { g_last_hip = (int)e_; return GOMEL_ERR_HIP; } \
     } while (0)
 
+// No C++ exception crosses the C boundary: every entry point that can allocate on the host runs inside this pair.
+#define GOMEL_TRY try {
+#define GOMEL_CATCH                                              \
+    } catch (const std::bad_alloc&) { return GOMEL_ERR_NO_MEMORY; } \
+    catch (...) { return GOMEL_ERR_NO_MEMORY; }
+
 struct TableHeader {
     uint32_t magic, version;
     int32_t n, hop, k, hann_periodic;
@@ -161,7 +167,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GOMEL_ERR_NO_DEVICE;
     gomel_handle* h = new (std::nothrow) gomel_handle();
-    if (!h) return GOMEL_ERR_HIP;
+    if (!h) return GOMEL_ERR_NO_MEMORY;
     h->cfg = *cfg;
     if (cfg->device >= 0) {
         if (cfg->device >= ndev) { delete h; return GOMEL_ERR_NO_DEVICE; }
@@ -215,6 +221,9 @@ struct PinRegistry {
             it->second.second++;
             return true;
         }
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return false;  // device / already pinned
+        (void)hipGetLastError();
         const bool ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
         if (ok) live.emplace(p, std::make_pair(bytes, 1));
@@ -287,6 +296,11 @@ static void batch_free(gomel_batch* b) {
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
     delete b;
 }
+
+struct BatchGuard {   // frees a half-built batch on every early exit, exceptions included
+    gomel_batch* b;
+    ~BatchGuard() { if (b) batch_free(b); }
+};
 
 // The fused kernel needs hop = SH * (N/16) with SH in the instantiated set.
 static int fused_shift(const gomel_config& c) {
@@ -486,6 +500,7 @@ const char* gomel_strerror(int s) {
         case GOMEL_ERR_NO_DEVICE: return "no usable HIP device";
         case GOMEL_ERR_BAD_TABLES: return "table blob does not match the configuration";
         case GOMEL_ERR_TOO_SHORT: return "padded input shorter than one frame";
+        case GOMEL_ERR_NO_MEMORY: return "host allocation failed";
         default: return "unknown status";
     }
 }
@@ -498,10 +513,10 @@ int gomel_default_config(gomel_config* c) {
     return GOMEL_OK;
 }
 
-int gomel_create(const gomel_config* cfg, gomel_handle** out) { return create_common(cfg, nullptr, 0, out); }
+int gomel_create(const gomel_config* cfg, gomel_handle** out) { GOMEL_TRY return create_common(cfg, nullptr, 0, out); GOMEL_CATCH }
 int gomel_create_from_tables(const gomel_config* cfg, const void* blob, size_t n, gomel_handle** out) {
     if (!blob) return GOMEL_ERR_NULL;
-    return create_common(cfg, blob, n, out);
+    GOMEL_TRY return create_common(cfg, blob, n, out); GOMEL_CATCH
 }
 
 size_t gomel_tables_bytes(const gomel_handle* h) {
@@ -522,7 +537,7 @@ int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap) {
     return GOMEL_OK;
 }
 
-int gomel_set_window(gomel_handle* h, const double* w, size_t n) {
+static int set_window_guarded(gomel_handle* h, const double* w, size_t n) {
     if (!h || !w) return GOMEL_ERR_NULL;
     if (n != (size_t)h->cfg.resolut) return GOMEL_ERR_BAD_LENGTH;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -593,7 +608,7 @@ int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.g
     return gomel_pad_len(orig, window) == padded ? 1 : 0;
 }
 
-int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
     if (!h || !n_pairs || !out) return GOMEL_ERR_NULL;
     *out = nullptr;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
@@ -606,7 +621,8 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(hipSetDevice(h->device));
     gomel_batch* b = new (std::nothrow) gomel_batch();
-    if (!b) return GOMEL_ERR_HIP;
+    if (!b) return GOMEL_ERR_NO_MEMORY;
+    BatchGuard guard{b};
     b->h = h; b->n_utt = n_utt;
     b->utts.resize(n_utt); b->n_pairs.assign(n_pairs, n_pairs + n_utt);
     for (size_t u = 0; u < n_utt; u++) {
@@ -659,7 +675,8 @@ int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gom
             for (int f = 0; f < b->utts[u].frames; f++) fx[(size_t)b->utts[u].fbase + f] = b->utts[u].xoff + (int64_t)f * hop;
         if (hipMemcpy(b->d_frame_xoff, fx.data(), fx.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
     }
-    if (rc) { batch_free(b); return rc; }
+    if (rc) return rc;
+    guard.b = nullptr;
     *out = b;
     return GOMEL_OK;
 }
@@ -683,10 +700,10 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
         }
     int64_t poff = 0;
     for (size_t u = 0; u < b->n_utt; u++) {
-        HIPCHK(hipMemcpyAsync(b->d_mel + poff * 2, mel[u], b->n_pairs[u] * 16, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(b->d_mel + poff * 2, mel[u], b->n_pairs[u] * 16, hipMemcpyDefault, h->stream));
         poff += (int64_t)b->n_pairs[u];
         if (b->utts[u].has_x0)
-            HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->stream));
     }
     HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, h->stream));
     if (wait || pin_here) HIPCHK(hipStreamSynchronize(h->stream));   // the local pins must outlive the copies
@@ -694,21 +711,21 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
     return GOMEL_OK;
 }
 
-int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
+static int batch_upload_guarded(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
     if (!b || !mel) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
     HIPCHK(hipSetDevice(b->h->device));
     return batch_upload_impl(b, mel, x0, seeds, true, true);
 }
 
-int gomel_batch_run(gomel_batch* b) {
+static int batch_run_guarded(gomel_batch* b) {
     if (!b) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
     HIPCHK(hipSetDevice(b->h->device));
     return batch_run_impl(b, nullptr);
 }
 
-int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t) {
+static int batch_run_timed_guarded(gomel_batch* b, gomel_timing* t) {
     if (!b || !t) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
     HIPCHK(hipSetDevice(b->h->device));
@@ -723,7 +740,7 @@ int gomel_batch_sync(gomel_batch* b) {
     return GOMEL_OK;
 }
 
-int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap) {
+static int batch_download_guarded(gomel_batch* b, double* const* out, const size_t* out_cap) {
     if (!b || !out) return GOMEL_ERR_NULL;
     gomel_handle* h = b->h;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -735,7 +752,7 @@ int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_c
     PinnedScope pins;
     for (size_t u = 0; u < b->n_utt; u++) pins.pin(out[u], (size_t)b->utts[u].len * 8);
     for (size_t u = 0; u < b->n_utt; u++)
-        HIPCHK(hipMemcpyAsync(out[u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(out[u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return GOMEL_OK;
 }
@@ -751,7 +768,7 @@ int gomel_batch_destroy(gomel_batch* b) {
 
 // Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances: chunk i computes on the
 // compute stream while chunk i-1's waveforms go back over PCIe on the copy stream (all caller buffers pinned for the call).
-int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
+static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
                          const uint64_t* seeds, double* const* out, const size_t* out_cap) {
     if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
@@ -782,7 +799,12 @@ int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel
         for (size_t i = 1; i < bounds.size(); i++) if (bounds[i] <= bounds[i - 1] || bounds[i] > n_utt) { bounds.assign({0, n_utt}); break; }
         n_chunks = (int)bounds.size() - 1;
     }
-    std::vector<gomel_batch*> chunks((size_t)n_chunks, nullptr);
+    struct ChunkList {
+        std::vector<gomel_batch*> v;
+        ~ChunkList() { for (gomel_batch* b : v) if (b) gomel_batch_destroy(b); }
+    } chunk_list;
+    std::vector<gomel_batch*>& chunks = chunk_list.v;
+    chunks.assign((size_t)n_chunks, nullptr);
     int rc = GOMEL_OK;
     for (int c = 0; c < n_chunks && !rc; c++) rc = gomel_batch_create(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], &chunks[c]);
     if (!rc) {
@@ -805,14 +827,13 @@ int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel
             if (!rc && (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], h->stream) != hipSuccess ||
                         hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
             for (size_t u = 0; u < b->n_utt && !rc; u++)
-                if (hipMemcpyAsync(out[u0 + u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess)
+                if (hipMemcpyAsync(out[u0 + u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->copy_stream) != hipSuccess)
                     rc = GOMEL_ERR_HIP;
         }
         if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
         if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
         for (hipEvent_t e : done) if (e) hipEventDestroy(e);
     }
-    for (gomel_batch* b : chunks) if (b) gomel_batch_destroy(b);
     return rc;
 }
 
@@ -834,7 +855,7 @@ int gomel_from_mel(gomel_handle* h, const double* mel, size_t n_pairs, const dou
 int gomel_rfft_frames(gomel_handle* h, const float* frames, size_t n_frames, float* spectrum) { return fft_hook(h, false, frames, n_frames, spectrum); }
 int gomel_irfft_frames(gomel_handle* h, const float* spectrum, size_t n_frames, float* frames) { return fft_hook(h, true, spectrum, n_frames, frames); }
 
-int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, float* mag_out) {
+static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t n_pairs, float* mag_out) {
     if (!h || !mel || !mag_out) return GOMEL_ERR_NULL;
     if (n_pairs == 0) return GOMEL_ERR_EMPTY;
     const int K = h->cfg.num_mels, N = h->cfg.resolut, H = N / 2;
@@ -955,7 +976,7 @@ int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_
     return rc;
 }
 
-int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out, size_t out_cap,
+static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out, size_t out_cap,
                      size_t* out_len) {
     if (!h || !pairs || !out) return GOMEL_ERR_NULL;
     const gomel_config& c = h->cfg;
@@ -995,6 +1016,37 @@ int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, co
     if (d_out) hipFree(d_out);
     if (!rc && out_len) *out_len = L;
     return rc;
+}
+
+// ---- exception firewall: the entry points that allocate on the host
+int gomel_set_window(gomel_handle* h, const double* w, size_t n) {
+    GOMEL_TRY return set_window_guarded(h, w, n); GOMEL_CATCH
+}
+int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+    GOMEL_TRY return batch_create_guarded(h, n_utt, n_pairs, out); GOMEL_CATCH
+}
+int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
+    GOMEL_TRY return batch_upload_guarded(b, mel, x0, seeds); GOMEL_CATCH
+}
+int gomel_batch_run(gomel_batch* b) {
+    GOMEL_TRY return batch_run_guarded(b); GOMEL_CATCH
+}
+int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t) {
+    GOMEL_TRY return batch_run_timed_guarded(b, t); GOMEL_CATCH
+}
+int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap) {
+    GOMEL_TRY return batch_download_guarded(b, out, out_cap); GOMEL_CATCH
+}
+int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
+                         const uint64_t* seeds, double* const* out, const size_t* out_cap) {
+    GOMEL_TRY return from_mel_batch_guarded(h, n_utt, mel, n_pairs, x0, seeds, out, out_cap); GOMEL_CATCH
+}
+int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, float* mag_out) {
+    GOMEL_TRY return target_magnitudes_guarded(h, mel, n_pairs, mag_out); GOMEL_CATCH
+}
+int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out, size_t out_cap,
+                     size_t* out_len) {
+    GOMEL_TRY return from_phase_guarded(h, num_freqs, volume_boost, pairs, n_pairs, out, out_cap, out_len); GOMEL_CATCH
 }
 
 }  // extern "C"

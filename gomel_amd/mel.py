@@ -22,6 +22,19 @@ class ErrFileNotLoaded(Exception):
         super().__init__("wavNotLoaded")
 
 
+def _is_device_tensor(a):
+    """A torch CUDA tensor: its memory is handed to the library as a device pointer (include/gomel_hip.h "Pointers")."""
+    return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
+
+
+def _device_ptr(a, numel, what):
+    import torch
+    if a.dtype != torch.float64 or not a.is_contiguous() or a.numel() != numel:
+        raise ValueError("%s: device tensors must be contiguous float64 with %d elements" % (what, numel))
+    torch.cuda.current_stream(a.device).synchronize()   # the library copies on its own stream
+    return ctypes.cast(ctypes.c_void_p(a.data_ptr()), c_double_p)
+
+
 def _as_pairs(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if a.ndim != 2 or a.shape[1] != 2:
@@ -181,19 +194,25 @@ class Batch:
         self._keep = None
 
     def upload(self, mels, x0s=None, seeds=None):
+        """Each spectrogram / x0 is a host array (numpy) or a torch CUDA tensor of the engine's device (float64, contiguous):
+        device tensors are copied HBM -> HBM, nothing crosses PCIe."""
         n = len(self.n_pairs)
-        ms = [_as_pairs(m) for m in mels]
-        if len(ms) != n or any(len(m) != k for m, k in zip(ms, self.n_pairs)):
+        if len(mels) != n:
             raise ValueError("mel shapes do not match the batch plan")
-        mp = (c_double_p * n)(*[m.ctypes.data_as(c_double_p) for m in ms])
+        ms = [m if _is_device_tensor(m) else _as_pairs(m) for m in mels]
+        if any((not _is_device_tensor(m)) and len(m) != k for m, k in zip(ms, self.n_pairs)):
+            raise ValueError("mel shapes do not match the batch plan")
+        mp = (c_double_p * n)(*[_device_ptr(m, 2 * k, "mel") if _is_device_tensor(m) else m.ctypes.data_as(c_double_p)
+                                for m, k in zip(ms, self.n_pairs)])
         xp = None
         xs = None
         if x0s is not None:
-            xs = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in x0s]
+            xs = [x if (x is None or _is_device_tensor(x)) else np.ascontiguousarray(x, dtype=np.float64) for x in x0s]
             for x, L in zip(xs, self.lens):
-                if x is not None and x.shape != (L,):
+                if x is not None and not _is_device_tensor(x) and x.shape != (L,):
                     raise ValueError("x0 length mismatch")
-            xp = (c_double_p * n)(*[None if x is None else x.ctypes.data_as(c_double_p) for x in xs])
+            xp = (c_double_p * n)(*[None if x is None else (_device_ptr(x, L, "x0") if _is_device_tensor(x) else x.ctypes.data_as(c_double_p))
+                                    for x, L in zip(xs, self.lens)])
         sp = None
         if seeds is not None:
             sp = (ctypes.c_uint64 * n)(*[int(s) & (2 ** 64 - 1) for s in seeds])
@@ -215,13 +234,15 @@ class Batch:
 
     def download(self, outs=None):
         """Copy the waveforms back.  `outs` may be a list of preallocated float64 arrays (caller-owned buffers, as the Go
-        side would pass); otherwise fresh arrays are returned."""
+        side would pass) or torch CUDA tensors (the audio stays in HBM); otherwise fresh arrays are returned."""
         n = len(self.n_pairs)
         if outs is None:
             outs = [np.empty(L, dtype=np.float64) for L in self.lens]
-        elif len(outs) != n or any(o.dtype != np.float64 or o.shape != (L,) or not o.flags.c_contiguous for o, L in zip(outs, self.lens)):
-            raise ValueError("outs must be C-contiguous float64 arrays of the planned lengths")
-        op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
+        elif len(outs) != n or any((not _is_device_tensor(o)) and (o.dtype != np.float64 or o.shape != (L,) or not o.flags.c_contiguous)
+                                   for o, L in zip(outs, self.lens)):
+            raise ValueError("outs must be C-contiguous float64 arrays (or CUDA tensors) of the planned lengths")
+        op = (c_double_p * n)(*[_device_ptr(o, L, "out") if _is_device_tensor(o) else o.ctypes.data_as(c_double_p)
+                                for o, L in zip(outs, self.lens)])
         caps = (ctypes.c_size_t * n)(*self.lens)
         check(_lib.lib().gomel_batch_download(self._b, op, caps), "gomel_batch_download")
         return outs

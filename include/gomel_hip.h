@@ -11,6 +11,10 @@
  * channel c of mel band k of frame f (producer domel mel/impl.go:313-341, consumer undomel mel/impl.go:350).
  * Waveforms are `double[L]`, L = Resolut + (F-1)*Window (mel/mel.go:80).
  *
+ * Pointers: `mel_pairs`, `x0` and `out` of gomel_from_mel, gomel_from_mel_batch, gomel_batch_upload and
+ * gomel_batch_download may each be host memory (pageable or pinned) or memory of the handle's device (a pipeline that
+ * keeps its spectrograms in HBM hands over device pointers; the copies are hipMemcpyDefault).  Everything else is host.
+ *
  * Threading: a handle may be used from concurrent host threads; calls on one handle are serialised by an
  * internal mutex and every entry sets the HIP device of the handle on the calling thread.
  */
@@ -38,7 +42,8 @@ typedef enum gomel_status {
     GOMEL_ERR_HIP = 8,            /* a HIP runtime call failed; gomel_last_hip_error() has the hipError_t         */
     GOMEL_ERR_NO_DEVICE = 9,
     GOMEL_ERR_BAD_TABLES = 10,    /* injected table blob does not match the configuration                         */
-    GOMEL_ERR_TOO_SHORT = 11      /* ToMel: padded input shorter than one frame                                   */
+    GOMEL_ERR_TOO_SHORT = 11,     /* ToMel: padded input shorter than one frame                                   */
+    GOMEL_ERR_NO_MEMORY = 12      /* host allocation failed (C++ exceptions never cross the boundary)             */
 } gomel_status;
 
 /* Mirrors `type Mel` (mel/mel.go:10-27).  YReverse, VolumeBoost and SampleRate only matter to the PNG/WAV

@@ -93,6 +93,7 @@ def test_config_validation_statuses(L):
         assert L.gomel_create(ctypes.byref(c), ctypes.byref(h)) == status, field
     assert L.gomel_create(None, ctypes.byref(h)) == 7
     assert b"NumMels" in L.gomel_strerror(3) and L.gomel_strerror(0) == b"ok" and L.gomel_strerror(999) == b"unknown status"
+    assert all(L.gomel_strerror(s) != b"unknown status" for s in range(13))      # every code of the header has a message
 
 
 def test_product_never_imports_the_oracle():

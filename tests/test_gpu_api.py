@@ -258,3 +258,33 @@ def test_threads_sharing_one_input_buffer(oracle):
     for t in ts:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_device_resident_inputs_and_outputs(oracle):
+    """Spectrograms, x0 and the output may live in HBM (torch CUDA tensors -> device pointers through the C ABI): same bits
+    as the host-buffer route, mixed host/device batches included."""
+    import torch
+    import gomel_amd
+    m = mel_obj(FIELDS["towav_n4096"], GriffinLimIterations=2)
+    e = m.engine()
+    mels = [oracle.random_logmel(f, 192, seed=20 + i) for i, f in enumerate((40, 400, 3))]   # 400 frames: above the pin threshold
+    lens = [e.out_len(len(x)) for x in mels]
+    x0s = [oracle.x0_splitmix(7, lens[0]), None, oracle.x0_splitmix(8, lens[2])]
+    b = gomel_amd.Batch(e, [len(x) for x in mels])
+    b.upload(mels, x0s, [1, 2, 3])
+    b.run()
+    want = b.download()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_mels = [torch.from_numpy(x).to(dev) for x in mels]
+    d_x0s = [torch.from_numpy(x0s[0]).to(dev), None, x0s[2]]                               # device, absent, host
+    b.upload([d_mels[0], mels[1], d_mels[2]], d_x0s, [1, 2, 3])                             # mixed host / device
+    b.run()
+    d_outs = [torch.empty(L, dtype=torch.float64, device=dev) for L in lens]
+    got = b.download([d_outs[0], np.empty(lens[1]), d_outs[2]])
+    for g, w in zip(got, want):
+        g = g.cpu().numpy() if hasattr(g, "cpu") else g
+        assert np.array_equal(g, w)
+    with pytest.raises(ValueError):
+        b.upload([d_mels[0].float(), mels[1], d_mels[2]], None, [1, 2, 3])                  # wrong dtype on the device
+    b.close()
+    e.close()

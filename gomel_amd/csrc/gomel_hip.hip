@@ -38,6 +38,49 @@ struct TableHeader {
 };
 static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
 
+// Device-buffer cache of one handle.  hipFree of a multi-megabyte buffer is synchronous and slow (0.6 ms of the 0.75 ms that
+// one 342-frame, 2-iteration FromMel call took host-to-host went into freeing its working set), and the Go API is one call
+// per utterance: freed buffers are kept and handed out again to requests of similar size.  Guarded by the handle's mutex.
+struct DevPool {
+    struct Block { void* p; size_t bytes; bool used; uint64_t stamp; };
+    std::vector<Block> blocks;
+    size_t cached = 0, cap = (size_t)4 << 30;   // bytes kept while unused (GOMEL_POOL_MB; 0 = no caching)
+    uint64_t clock = 0;
+    hipError_t alloc(void** out, size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        int best = -1;
+        for (size_t i = 0; i < blocks.size(); i++) {
+            const Block& k = blocks[i];
+            if (!k.used && k.bytes >= bytes && k.bytes <= bytes + bytes / 2 + 65536 && (best < 0 || k.bytes < blocks[best].bytes)) best = (int)i;
+        }
+        if (best >= 0) { blocks[best].used = true; cached -= blocks[best].bytes; *out = blocks[best].p; return hipSuccess; }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = hipMalloc(out, bytes); }   // give the cache back and retry
+        if (e == hipSuccess) blocks.push_back(Block{*out, bytes, true, 0});
+        return e;
+    }
+    void release(void* p) {
+        for (Block& k : blocks)
+            if (k.p == p) { k.used = false; k.stamp = ++clock; cached += k.bytes; trim(cap); return; }
+        (void)hipFree(p);   // not ours (never happens): plain free
+    }
+    void trim(size_t keep) {   // drop the least recently released buffers until at most `keep` bytes stay cached
+        while (cached > keep) {
+            int old = -1;
+            for (size_t i = 0; i < blocks.size(); i++)
+                if (!blocks[i].used && (old < 0 || blocks[i].stamp < blocks[old].stamp)) old = (int)i;
+            if (old < 0) break;
+            (void)hipFree(blocks[old].p);
+            cached -= blocks[old].bytes;
+            blocks.erase(blocks.begin() + old);
+        }
+    }
+    void clear() {
+        for (Block& k : blocks) (void)hipFree(k.p);
+        blocks.clear(); cached = 0;
+    }
+};
+
 struct gomel_handle {
     gomel_config cfg;
     int device = 0;
@@ -51,6 +94,7 @@ struct gomel_handle {
     std::vector<BinRow> undo;     // [N/2]
     std::vector<BinRow> dom;      // [K]
     void* d_blob = nullptr;       // one device allocation for all tables
+    DevPool pool;                 // working buffers of batches and of the one-shot entry points
     DevTables dt{};
 };
 
@@ -169,6 +213,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     gomel_handle* h = new (std::nothrow) gomel_handle();
     if (!h) return GOMEL_ERR_NO_MEMORY;
     h->cfg = *cfg;
+    if (const char* e = getenv("GOMEL_POOL_MB")) h->pool.cap = (size_t)std::max(0L, atol(e)) << 20;
     if (cfg->device >= 0) {
         if (cfg->device >= ndev) { delete h; return GOMEL_ERR_NO_DEVICE; }
         h->device = cfg->device;
@@ -291,7 +336,7 @@ static void batch_free(gomel_batch* b) {
     hipSetDevice(b->h->device);
     void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
                     b->d_segs, b->d_tail[0], b->d_tail[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
-    for (void* p : ptrs) if (p) hipFree(p);
+    for (void* p : ptrs) if (p) b->h->pool.release(p);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
     delete b;
@@ -458,8 +503,8 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     const int N = h->cfg.resolut;
     const size_t in_b = n_frames * (inverse ? (size_t)(N + 2) : (size_t)N) * 4, out_b = n_frames * (inverse ? (size_t)N : (size_t)(N + 2)) * 4;
     float *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc(&d_in, in_b));
-    if (hipMalloc(&d_out, out_b) != hipSuccess) { hipFree(d_in); return GOMEL_ERR_HIP; }
+    HIPCHK(h->pool.alloc((void**)&d_in, in_b));
+    if (h->pool.alloc((void**)&d_out, out_b) != hipSuccess) { h->pool.release(d_in); return GOMEL_ERR_HIP; }
     int rc = GOMEL_OK;
     if (hipMemcpyAsync(d_in, in, in_b, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
@@ -470,7 +515,7 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
             g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
         }
     }
-    hipFree(d_in); hipFree(d_out);
+    h->pool.release(d_in); h->pool.release(d_out);
     return rc;
 }
 
@@ -574,6 +619,7 @@ int gomel_destroy(gomel_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    h->pool.clear();
     if (h->d_blob) hipFree(h->d_blob);
     delete h;
     return GOMEL_OK;
@@ -640,7 +686,7 @@ static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_p
     b->fast = (!b->precise && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames > 512)) ? 1 : 0;
     const int I = c.griffin_lim_iterations;
     int rc = GOMEL_OK;
-    auto alloc = [&](void** p, size_t bytes) { if (!rc && hipMalloc(p, bytes ? bytes : 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
+    auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
     alloc((void**)&b->d_mel, (size_t)b->total_pairs * 16);
     alloc((void**)&b->d_out, (size_t)b->total_len * 8);
     alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
@@ -691,7 +737,7 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
         b->utts[u].seed = seeds ? seeds[u] : (uint64_t)u;
         b->any_x0 |= b->utts[u].has_x0 != 0;
     }
-    if (b->any_x0 && !b->d_x0) HIPCHK(hipMalloc((void**)&b->d_x0, (size_t)b->total_len * 8));
+    if (b->any_x0 && !b->d_x0) HIPCHK(h->pool.alloc((void**)&b->d_x0, (size_t)b->total_len * 8));
     PinnedScope pins;
     if (pin_here)
         for (size_t u = 0; u < b->n_utt; u++) {
@@ -865,8 +911,8 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
     HIPCHK(hipSetDevice(h->device));
     double* d_mel = nullptr; float *d_mag = nullptr, *d_nyq = nullptr;
     int rc = GOMEL_OK;
-    if (hipMalloc((void**)&d_mel, n_pairs * 16) != hipSuccess || hipMalloc((void**)&d_mag, F * H * 4) != hipSuccess ||
-        hipMalloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (h->pool.alloc((void**)&d_mel, n_pairs * 16) != hipSuccess || h->pool.alloc((void**)&d_mag, F * H * 4) != hipSuccess ||
+        h->pool.alloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc && hipMemcpyAsync(d_mel, mel, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
         launch_mel_to_mag<float>(N, (unsigned)F, (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
@@ -883,9 +929,9 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
                 mag_out[f * (H + 1) + H] = ny[f];
             }
     }
-    if (d_mel) hipFree(d_mel);
-    if (d_mag) hipFree(d_mag);
-    if (d_nyq) hipFree(d_nyq);
+    if (d_mel) h->pool.release(d_mel);
+    if (d_mag) h->pool.release(d_mag);
+    if (d_nyq) h->pool.release(d_nyq);
     return rc;
 }
 
@@ -911,8 +957,8 @@ int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pair
     HIPCHK(hipSetDevice(h->device));
     double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
-    if (hipMalloc((void**)&d_wave, P * 8) != hipSuccess || hipMalloc((void**)&d_smag, F * (size_t)(H + 1) * 8) != hipSuccess ||
-        hipMalloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, F * (size_t)(H + 1) * 8) != hipSuccess ||
+        h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
                 hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
     if (!rc) {
@@ -923,9 +969,9 @@ int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pair
         if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     }
-    if (d_wave) hipFree(d_wave);
-    if (d_smag) hipFree(d_smag);
-    if (d_out) hipFree(d_out);
+    if (d_wave) h->pool.release(d_wave);
+    if (d_smag) h->pool.release(d_smag);
+    if (d_out) h->pool.release(d_out);
     if (!rc && n_pairs) *n_pairs = pairs;
     return rc;
 }
@@ -960,7 +1006,7 @@ int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_
     HIPCHK(hipSetDevice(h->device));
     double *d_wave = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
-    if (hipMalloc((void**)&d_wave, P * 8) != hipSuccess || hipMalloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
                 hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
     if (!rc) {
@@ -970,8 +1016,8 @@ int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_
         if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     }
-    if (d_wave) hipFree(d_wave);
-    if (d_out) hipFree(d_out);
+    if (d_wave) h->pool.release(d_wave);
+    if (d_out) h->pool.release(d_out);
     if (!rc && n_pairs) *n_pairs = pairs;
     return rc;
 }
@@ -998,8 +1044,8 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
     HIPCHK(hipSetDevice(h->device));
     double *d_in = nullptr, *d_yw = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
-    if (hipMalloc((void**)&d_in, n_pairs * 16) != hipSuccess || hipMalloc((void**)&d_yw, F * (size_t)N * 8) != hipSuccess ||
-        hipMalloc((void**)&d_out, L * 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+    if (h->pool.alloc((void**)&d_in, n_pairs * 16) != hipSuccess || h->pool.alloc((void**)&d_yw, F * (size_t)N * 8) != hipSuccess ||
+        h->pool.alloc((void**)&d_out, L * 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && hipMemcpyAsync(d_in, pairs, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
         if (N == 4096) hipLaunchKernelGGL(k_phase_istft<4096>, dim3((unsigned)F), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
@@ -1011,9 +1057,9 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
             g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
         }
     }
-    if (d_in) hipFree(d_in);
-    if (d_yw) hipFree(d_yw);
-    if (d_out) hipFree(d_out);
+    if (d_in) h->pool.release(d_in);
+    if (d_yw) h->pool.release(d_yw);
+    if (d_out) h->pool.release(d_out);
     if (!rc && out_len) *out_len = L;
     return rc;
 }

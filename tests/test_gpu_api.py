@@ -288,3 +288,31 @@ def test_device_resident_inputs_and_outputs(oracle):
         b.upload([d_mels[0].float(), mels[1], d_mels[2]], None, [1, 2, 3])                  # wrong dtype on the device
     b.close()
     e.close()
+
+
+def test_working_buffers_reused_across_calls_leave_no_trace(oracle):
+    """A handle keeps the device buffers of finished calls and hands them out again (hipFree is the slowest part of a short
+    call).  Results must not depend on what a recycled buffer held: every sequence below is compared, bit for bit, with the
+    same call on a fresh handle."""
+    import gomel_amd
+    fields = FIELDS["towav_n4096"]
+
+    def run(e, frames, seed, path):
+        e.set_path(path)
+        mels = [oracle.random_logmel(f, 192, seed=seed + i) for i, f in enumerate(frames)]
+        return e.from_mel_batch(mels, None, [seed + 10 * i for i in range(len(frames))])
+
+    plan = [((300, 280, 41), 1, 0), ((200, 390), 5, 0), ((37,), 9, 0), ((210, 200, 199), 3, 1), ((16, 900), 7, 0), ((300, 280, 41), 1, 0)]
+    shared = mel_obj(fields, GriffinLimIterations=3).engine()
+    for frames, seed, path in plan:
+        got = run(shared, frames, seed, path)
+        fresh = mel_obj(fields, GriffinLimIterations=3).engine()
+        want = run(fresh, frames, seed, path)
+        fresh.close()
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), (frames, seed, path)
+    wave = oracle.config2_signal(44100, 0.4)
+    a = shared.to_mel(wave)                                   # ToMel's temporaries come from the same cache
+    fresh = mel_obj(fields, GriffinLimIterations=3).engine()
+    assert np.array_equal(a, fresh.to_mel(wave))
+    fresh.close()
+    shared.close()

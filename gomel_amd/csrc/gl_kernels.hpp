@@ -46,39 +46,75 @@ GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
 }
 
 // =============================================================================================== K1: log-mel -> target magnitudes
-// One block per frame.  mag[f][slot(k)] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from
-// channel 1 at bin N/2-1 (the only survivor of channel 1).  fp64 arithmetic, fp32 result.
+// mag[f][slot(k)] = |(undomel(exp(mel))[k][0] - TuneAdd)/TuneMul| / N for k < N/2, nyq[f] the same from channel 1 at bin
+// N/2-1 (the only survivor of channel 1).  fp64 arithmetic, fp32 (or fp64) result.
+// A block walks kMagFramesPerBlock consecutive frames: each thread keeps the table rows of its N/512 bins in registers
+// (one table read per block, not per frame); exp() of channel 0 of all the block's frames is taken first, in full rounds of
+// 256 lanes, into LDS; each row is assembled in LDS in lane-slot order (gl_fft.hpp) and leaves as one coalesced stream.
+// Channel 1 feeds bin N/2-1 only, so its exp() is taken for the one or two bands that row reads, not for all K (the fp64
+// exp() was what bounded this kernel).  Reads K*16 B, writes (N/2+1)*4 B per frame.
+constexpr int kMagFramesPerBlock = 8;
+
+GL_DEV double apply_row_ch1(const BinRow r, const double* __restrict__ m) {   // apply_row on exp(channel 1), straight from the pairs
+    if (r.mode == 0) return exp(m[2 * r.lo + 1]);
+    if (r.mode == 1) return exp(m[2 * r.lo + 1]) * (1 - r.modlo) + exp(m[2 * r.hi + 1]) * r.modlo;
+    double tot = 0;
+    for (int k = r.lo; k < r.hi; k++) tot += exp(m[2 * k + 1]);
+    return tot / r.div;
+}
+
 template <int N, class MagT>
 __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
-                                                    MagT* __restrict__ mag, MagT* __restrict__ nyq, int K,
+                                                    MagT* __restrict__ mag, MagT* __restrict__ nyq, int K, int64_t n_frames,
                                                     double tune_add, double tune_mul, double inv_n) {
-    constexpr int H = N / 2;
-    extern __shared__ double e_sh[];  // [2][K]
-    const int64_t f = blockIdx.x;
-    const double* m = mel + f * (int64_t)K * 2;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        e_sh[k] = exp(m[2 * k]);
-        e_sh[K + k] = exp(m[2 * k + 1]);
+    constexpr int H = N / 2, PER = H / 256, FPB = kMagFramesPerBlock;
+    extern __shared__ double e_sh[];                       // [FPB][K] exp(channel 0), then the staged row [H] of MagT
+    MagT* row = reinterpret_cast<MagT*>(e_sh + FPB * K);
+    BinRow r[PER];
+    int slot[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        r[j] = undo[threadIdx.x + 256 * j];
+        slot[j] = mag_slot_index<Geo<N>>(threadIdx.x + 256 * j);
     }
+    const bool unit_mul = tune_mul == 1.0;                 // kernel-argument uniform
+    const int64_t f0 = (int64_t)blockIdx.x * FPB;
+    const int nf = (int)(n_frames - f0 < FPB ? n_frames - f0 : FPB);
+    const double* m0 = mel + f0 * (int64_t)K * 2;
+    for (int k = threadIdx.x; k < nf * K; k += 256) e_sh[k] = exp(m0[2 * k]);   // frame-major: e_sh[ff*K + band]
     __syncthreads();
-    for (int i = threadIdx.x; i < H; i += blockDim.x) {
-        const BinRow r = undo[i];
-        double v0 = (apply_row(r, e_sh) - tune_add) / tune_mul;
-        mag[f * H + mag_slot_index<Geo<N>>(i)] = (MagT)(fabs(v0) * inv_n);   // lane-slot order, see gl_fft.hpp
-        if (i == H - 1) {
-            double v1 = (apply_row(r, e_sh + K) - tune_add) / tune_mul;
-            nyq[f] = (MagT)(fabs(v1) * inv_n);
+    for (int ff = 0; ff < nf; ff++) {
+        const int64_t f = f0 + ff;
+        const double* e = e_sh + ff * K;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            // (v - TuneAdd) / TuneMul, mel/impl.go:396-397; x / 1.0 is x exactly, so the NewMel default skips the fp64 divide
+            double v0 = apply_row(r[j], e) - tune_add;
+            if (!unit_mul) v0 /= tune_mul;
+            row[slot[j]] = (MagT)(fabs(v0) * inv_n);
+            if (threadIdx.x + 256 * j == H - 1) {
+                double v1 = apply_row_ch1(r[j], m0 + (int64_t)ff * K * 2) - tune_add;
+                if (!unit_mul) v1 /= tune_mul;
+                nyq[f] = (MagT)(fabs(v1) * inv_n);
+            }
         }
+        __syncthreads();
+        MagT* o = mag + f * H;
+#pragma unroll
+        for (int j = 0; j < PER; j++) o[threadIdx.x + 256 * j] = row[threadIdx.x + 256 * j];
+        __syncthreads();                                   // the next frame overwrites the staged row
     }
 }
 
 template <class MagT>
-static void launch_mel_to_mag(int N, unsigned frames, size_t shmem, hipStream_t s, const double* mel, const BinRow* undo, MagT* mag, MagT* nyq,
+static void launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const double* mel, const BinRow* undo, MagT* mag, MagT* nyq,
                               int K, double tune_add, double tune_mul) {
     const double inv_n = 1.0 / (double)N;
-    if (N == 4096) hipLaunchKernelGGL((k_mel_to_mag<4096, MagT>), dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
-    else if (N == 2048) hipLaunchKernelGGL((k_mel_to_mag<2048, MagT>), dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
-    else hipLaunchKernelGGL((k_mel_to_mag<1024, MagT>), dim3(frames), dim3(256), shmem, s, mel, undo, mag, nyq, K, tune_add, tune_mul, inv_n);
+    const unsigned blocks = (unsigned)((frames + kMagFramesPerBlock - 1) / kMagFramesPerBlock);
+    const size_t shmem = (size_t)kMagFramesPerBlock * K * 8 + (size_t)(N / 2) * sizeof(MagT);
+    if (N == 4096) hipLaunchKernelGGL((k_mel_to_mag<4096, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n);
+    else if (N == 2048) hipLaunchKernelGGL((k_mel_to_mag<2048, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n);
+    else hipLaunchKernelGGL((k_mel_to_mag<1024, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n);
 }
 
 // =============================================================================================== K3: initial signal

@@ -429,7 +429,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
-            launch_mel_to_mag<double>(N, (unsigned)b->total_frames, (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
+            launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
             hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
@@ -446,7 +446,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
             HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
         } else {
-        launch_mel_to_mag<float>(N, (unsigned)b->total_frames, (size_t)K * 16, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
+        launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
         hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
@@ -915,7 +915,7 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
         h->pool.alloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc && hipMemcpyAsync(d_mel, mel, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        launch_mel_to_mag<float>(N, (unsigned)F, (size_t)K * 16, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
+        launch_mel_to_mag<float>(N, (int64_t)F, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
         std::vector<float> mg(F * H), ny(F);
         if (hipMemcpyAsync(mg.data(), d_mag, F * H * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipMemcpyAsync(ny.data(), d_nyq, F * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||

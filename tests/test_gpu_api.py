@@ -316,3 +316,38 @@ def test_working_buffers_reused_across_calls_leave_no_trace(oracle):
     assert np.array_equal(a, fresh.to_mel(wave))
     fresh.close()
     shared.close()
+
+
+def test_to_mel_tables_fuzz_against_oracle(oracle):
+    """Random band counts / band edges / FFT sizes / hops through ToMel (host-built domel table + fp64 STFT kernels) against the
+    oracle; configurations whose domel table runs past the bins (the reference panics) must come back as GOMEL_ERR_TABLE_RANGE."""
+    import gomel_amd
+    rng = np.random.default_rng(77)
+    sig = oracle.config2_signal(seconds=0.25)
+    ran = refused = 0
+    for trial in range(40):
+        N = int(rng.choice([1024, 2048, 4096]))
+        hop = int(rng.choice([N // 16, N // 8, N // 4, 2 * int(rng.integers(20, N // 4))]))
+        K = int(rng.integers(6, 300))
+        fields = dict(NumMels=K, MelFmin=float(rng.choice([0.0, rng.uniform(0, 300)])), MelFmax=float(rng.uniform(1500, 26000)), Window=hop, Resolut=N)
+        cfg = oracle.MelConfig(**fields)
+        x = sig[:int(rng.integers(N, len(sig)))]
+        try:
+            want = oracle.to_mel(cfg, x)
+        except (IndexError, ValueError):
+            want = None
+        m = mel_obj(fields)
+        if want is None:
+            with pytest.raises(gomel_amd.GomelError) as ei:
+                m.ToMel(x)
+            assert ei.value.status == 5, fields
+            refused += 1
+        else:
+            got = m.ToMel(x)
+            assert got.shape == want.shape, fields
+            bad = ~np.isfinite(want)
+            assert np.array_equal(bad, ~np.isfinite(got)), fields
+            assert np.max(np.abs(got[~bad] - want[~bad])) < 1e-9, fields
+            ran += 1
+        m.engine().close()
+    assert ran >= 20, (ran, refused)

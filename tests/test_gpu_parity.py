@@ -286,3 +286,73 @@ def test_precise_mode_is_the_fp64_algorithm(oracle, geom, frames, iters):
     assert rms(got - want) < 1e-10 * max(1.0, rms(want)), rms(got - want)
     m.engine().set_precision(32)
     assert 1e-10 < rms(m.FromMel(mel.copy(), x0=x0) - want) < RMS_TOL      # back to the fp32 kernels
+
+
+def test_mel_tables_fuzz_against_oracle(oracle):
+    """Random configurations (bands, fmin/fmax, tune, all three FFT sizes): the host-built undomel table + k_mel_to_mag against
+    the oracle's literal undomel -- including configurations whose table runs past the band slice, where the reference panics:
+    there the library must return GOMEL_ERR_TABLE_RANGE and the oracle must raise."""
+    import gomel_amd
+    rng = np.random.default_rng(2024)
+    ran = refused = 0
+    for trial in range(60):
+        N = int(rng.choice([1024, 2048, 4096]))
+        K = int(rng.integers(6, 400))
+        fmin = float(rng.choice([0.0, 0.0, rng.uniform(0, 400)]))
+        fmax = float(rng.uniform(1500, 26000))
+        add, mul = (0.0, 1.0) if trial % 3 == 0 else (float(rng.uniform(-0.05, 0.05)), float(rng.choice([-2.0, 0.5, 1.0, 3.0])))
+        fields = dict(NumMels=K, MelFmin=fmin, MelFmax=fmax, Window=N // 4, Resolut=N, TuneAdd=add, TuneMul=mul, GriffinLimIterations=1)
+        cfg = oracle.MelConfig(**fields)
+        mel = oracle.random_logmel(3, K, seed=trial)
+        try:
+            want = oracle.target_magnitudes(cfg, np.exp(mel)) / N
+        except (IndexError, ValueError):
+            want = None
+        m = gomel_amd.NewMel()
+        for k, v in fields.items():
+            setattr(m, k, v)
+        if want is None:
+            with pytest.raises(gomel_amd.GomelError) as ei:
+                m.engine().target_magnitudes(mel)
+            assert ei.value.status == 5, fields
+            refused += 1
+            continue
+        got = m.engine().target_magnitudes(mel)
+        bad = ~np.isfinite(want)
+        assert np.array_equal(bad, ~np.isfinite(got)), fields                       # the -0.0 / empty-sum NaN quirk, where it occurs
+        err = np.abs(got[~bad] - want[~bad]) / (np.abs(want[~bad]) + 1e-30)
+        assert err.max() < 2e-7, (fields, float(err.max()))
+        m.engine().close()
+        ran += 1
+    assert ran >= 30, (ran, refused)
+
+
+def test_from_mel_fuzz_configs(oracle):
+    """Random geometry through the whole FromMel path: any even hop up to N (fused where hop = SH*N/16, generic elsewhere), random
+    band layout, ragged frame counts, 0-3 iterations, both x0 routes."""
+    import gomel_amd
+    rng = np.random.default_rng(5150)
+    for trial in range(40):
+        N = int(rng.choice([1024, 2048, 4096]))
+        hop = int(rng.choice([N // 16, N // 4, 5 * N // 16, N // 2, N, 2 * int(rng.integers(8, N // 2))]))
+        K = int(rng.integers(8, 256))
+        I = int(rng.integers(0, 4))
+        F = int(rng.integers(1, 14))
+        fields = dict(NumMels=K, MelFmax=float(rng.uniform(4000, 22000)), Window=hop, Resolut=N, GriffinLimIterations=I)
+        cfg = oracle.MelConfig(**fields)
+        mel = oracle.random_logmel(F, K, seed=100 + trial)
+        L = oracle.out_len(cfg, len(mel))
+        x0 = oracle.x0_splitmix(trial, L)
+        try:
+            want = oracle.from_mel(cfg, mel.copy(), x0)
+        except (IndexError, ValueError):
+            continue                                      # table range: covered by test_mel_tables_fuzz_against_oracle
+        m = gomel_amd.NewMel()
+        for k, v in fields.items():
+            setattr(m, k, v)
+        got = m.FromMel(mel.copy(), x0=x0) if trial % 2 else m.FromMel(mel.copy(), seed=trial)
+        assert got.shape == want.shape, fields
+        assert np.all(np.isfinite(got)) == np.all(np.isfinite(want)), fields
+        if np.all(np.isfinite(want)):
+            assert rms(got - want) < RMS_TOL * max(1.0, rms(want)), (fields, F, rms(got - want))
+        m.engine().close()

@@ -3,7 +3,7 @@
 //   k_mel_to_mag      spectral_denormalize mel/impl.go:421-427 + undomel :347-384 + undospectrum :386-408
 //   k_init_x          random init mel/mel.go:80-83 (explicit x0 or documented splitmix64 generator)
 //   k_gl_fused        one Griffin-Lim iteration (mel/mel.go:87-136) over runs of consecutive frames, hop = SH*N/16
-//   k_gl_frames/k_ola the same iteration for any even hop: per-frame kernel + overlap-add (mel/mel.go:112-125,135)
+//   k_gl_frames/k_ola the same iteration for any hop: per-frame kernel + overlap-add (mel/mel.go:112-125,135)
 //   k_finalize, k_add_tails   float -> double output (mel/mel.go:138)
 //   k_stft_mag, k_domel_log   ToMel mel/mel.go:46-74, domel mel/impl.go:310-345, spectral_normalize :410-419
 //   k_phase_stft, k_phase_istft, k_phase_ola   phase.ToPhase / FromPhase, phase/phase.go:41-155
@@ -168,7 +168,10 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
         else __syncthreads();
     };
 
-    const v2f* xs = reinterpret_cast<const v2f*>(x + frame_xoff[frame]);  // hop and offsets are even: 8-byte aligned
+    // frames of an odd hop start on odd samples: the gather promises 4-byte alignment only (the hardware takes dword-aligned
+    // dwordx2 loads; where it does not, the compiler splits them)
+    typedef v2f v2f_a4 __attribute__((aligned(4)));
+    const v2f_a4* xs = reinterpret_cast<const v2f_a4*>(x + frame_xoff[frame]);
     const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
     v2f v[16], w[16], wn[8];
     MagRegs mr;
@@ -202,7 +205,8 @@ __global__ __launch_bounds__(128) void k_gl_frames_d(const double* __restrict__ 
     v2d* my = lds + stream * G::LDS_SLOTS;
     const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
     auto sync = [] { __syncthreads(); };
-    const v2d* xs = reinterpret_cast<const v2d*>(x + frame_xoff[frame]);
+    typedef v2d v2d_a8 __attribute__((aligned(8)));   // odd hops: 8-byte alignment only
+    const v2d_a8* xs = reinterpret_cast<const v2d_a8*>(x + frame_xoff[frame]);
     const v2d* w2 = reinterpret_cast<const v2d*>(tb.windowd);
     v2d v[16], wn[8];
     MagRegsD mr;

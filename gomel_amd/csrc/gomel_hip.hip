@@ -146,7 +146,6 @@ static int validate_config(const gomel_config* c) {
     if (c->num_mels <= 0 || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
     if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
     if (c->resolut != 1024 && c->resolut != 2048 && c->resolut != 4096) return GOMEL_ERR_UNSUPPORTED_N;
-    if (c->window % 2 != 0) return GOMEL_ERR_BAD_CONFIG;  // float2 (8-byte) frame loads need an even hop
     return GOMEL_OK;
 }
 
@@ -534,7 +533,7 @@ int gomel_device_count(void) {
 const char* gomel_strerror(int s) {
     switch (s) {
         case GOMEL_OK: return "ok";
-        case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax, or odd Window)";
+        case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax)";
         case GOMEL_ERR_UNSUPPORTED_N: return "Resolut must be 1024, 2048 or 4096";
         case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
         case GOMEL_ERR_EMPTY: return "empty input";

@@ -50,7 +50,7 @@ typedef enum gomel_status {
  * codec, which stays on the host side of the boundary (ToWavPng mel/mel.go:211-238). */
 typedef struct gomel_config {
     int32_t num_mels;               /* NumMels                                   default 160  */
-    int32_t window;                 /* Window  = hop (gossp frameShift)          default 256  */
+    int32_t window;                 /* Window  = hop (gossp frameShift), any > 0 default 256  */
     int32_t resolut;                /* Resolut = frame / FFT length N            default 2048 */
     int32_t griffin_lim_iterations; /* GriffinLimIterations                      default 2    */
     double mel_fmin;                /* MelFmin  default 0    */

@@ -7,7 +7,7 @@
 //  * An N-point real frame is packed as C = N/2 complex points z[n] = x[2n] + i x[2n+1]; one "stream" of
 //    T = C/16 lanes owns a frame, 16 complex points per lane, so x / window / overlap-add live in registers
 //    at pair index n = t + T*j (lane t, register j).
-//  * Three in-register passes R1 x R2 x R3 (16x16x8, 16x8x8, 8x8x8 for N = 4096, 2048, 1024) with two LDS
+//  * Three in-register passes R1 x R2 x R3 (16x16x8, 16x8x8, 8x8x8, 8x4x8, 4x4x8 for N = 4096, 2048, 1024, 512, 256) with two LDS
 //    exchanges (layouts A and B below, padded so the b64 reads of every pass are bank-conflict free).
 //  * The last pass is always radix-8 and each lane runs the two mirrored butterflies b and B3-b, so the bins
 //    k and C-k that the real-FFT split needs meet in ONE lane's registers: the split, the magnitude clamp /
@@ -52,6 +52,8 @@ template <int N_, int R1_, int R2_> struct GeoBase {
 template <> struct Geo<4096> : GeoBase<4096, 16, 16> {};
 template <> struct Geo<2048> : GeoBase<2048, 16, 8> {};
 template <> struct Geo<1024> : GeoBase<1024, 8, 8> {};
+template <> struct Geo<512> : GeoBase<512, 8, 4> {};
+template <> struct Geo<256> : GeoBase<256, 4, 4> {};
 
 // Device-side view of the twiddle tables (global memory or LDS; the code is the same).
 template <class V> struct Twiddles {
@@ -257,7 +259,9 @@ template <bool INV, int S, class V> GL_DEV void dft16(V* v) {
 }
 
 template <bool INV, int R, int S, class V> GL_DEV void dftR(V* v) {
-    if constexpr (R == 16) dft16<INV, S>(v); else dft8<INV, S>(v);
+    if constexpr (R == 16) dft16<INV, S>(v);
+    else if constexpr (R == 8) dft8<INV, S>(v);
+    else { static_assert(R == 4, "radix"); dft4<INV>(v[0], v[S], v[2 * S], v[3 * S]); }
 }
 
 // ---------------------------------------------------------------------------------------------- forward

@@ -37,6 +37,17 @@ struct DevTables {
     const BinRow* dom;     // [K]
 };
 
+// Every supported Resolut in one place: expands the statement with NN a compile-time constant.
+#define GOMEL_DISPATCH_N(n, ...)                                   \
+    switch (n) {                                                   \
+        case 4096: { constexpr int NN = 4096; __VA_ARGS__; } break; \
+        case 2048: { constexpr int NN = 2048; __VA_ARGS__; } break; \
+        case 1024: { constexpr int NN = 1024; __VA_ARGS__; } break; \
+        case 512:  { constexpr int NN = 512;  __VA_ARGS__; } break; \
+        default:   { constexpr int NN = 256;  __VA_ARGS__; } break; \
+    }
+static inline bool gomel_supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
     if (r.mode == 0) return e[r.lo];
     if (r.mode == 1) return e[r.lo] * (1 - r.modlo) + e[r.hi] * r.modlo;
@@ -67,16 +78,18 @@ template <int N, class MagT>
 __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
                                                     MagT* __restrict__ mag, MagT* __restrict__ nyq, int K, int64_t n_frames,
                                                     double tune_add, double tune_mul, double inv_n) {
-    constexpr int H = N / 2, PER = H / 256, FPB = kMagFramesPerBlock;
+    constexpr int H = N / 2, PER = H < 256 ? 1 : H / 256, FPB = kMagFramesPerBlock;   // N 256: half the block's lanes idle in the bin loops
     extern __shared__ double e_sh[];                       // [FPB][K] exp(channel 0), then the staged row [H] of MagT
     MagT* row = reinterpret_cast<MagT*>(e_sh + FPB * K);
     BinRow r[PER];
     int slot[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-        r[j] = undo[threadIdx.x + 256 * j];
-        slot[j] = mag_slot_index<Geo<N>>(threadIdx.x + 256 * j);
+        const int bin = threadIdx.x + 256 * j < H ? threadIdx.x + 256 * j : H - 1;
+        r[j] = undo[bin];
+        slot[j] = mag_slot_index<Geo<N>>(bin);
     }
+    const bool has_bin = (int)threadIdx.x < H;             // PER > 1 implies H >= 512: every lane has its bins
     const bool unit_mul = tune_mul == 1.0;                 // kernel-argument uniform
     const int64_t f0 = (int64_t)blockIdx.x * FPB;
     const int nf = (int)(n_frames - f0 < FPB ? n_frames - f0 : FPB);
@@ -88,6 +101,7 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
         const double* e = e_sh + ff * K;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
+            if (!has_bin) break;
             // (v - TuneAdd) / TuneMul, mel/impl.go:396-397; x / 1.0 is x exactly, so the NewMel default skips the fp64 divide
             double v0 = apply_row(r[j], e) - tune_add;
             if (!unit_mul) v0 /= tune_mul;
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
         __syncthreads();
         MagT* o = mag + f * H;
 #pragma unroll
-        for (int j = 0; j < PER; j++) o[threadIdx.x + 256 * j] = row[threadIdx.x + 256 * j];
+        for (int j = 0; j < PER; j++) if (has_bin) o[threadIdx.x + 256 * j] = row[threadIdx.x + 256 * j];
         __syncthreads();                                   // the next frame overwrites the staged row
     }
 }
@@ -112,9 +126,7 @@ static void launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const double
     const double inv_n = 1.0 / (double)N;
     const unsigned blocks = (unsigned)((frames + kMagFramesPerBlock - 1) / kMagFramesPerBlock);
     const size_t shmem = (size_t)kMagFramesPerBlock * K * 8 + (size_t)(N / 2) * sizeof(MagT);
-    if (N == 4096) hipLaunchKernelGGL((k_mel_to_mag<4096, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n);
-    else if (N == 2048) hipLaunchKernelGGL((k_mel_to_mag<2048, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n);
-    else hipLaunchKernelGGL((k_mel_to_mag<1024, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n);
+    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_mel_to_mag<NN, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n));
 }
 
 // =============================================================================================== K3: initial signal

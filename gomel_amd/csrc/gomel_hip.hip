@@ -145,7 +145,7 @@ static int validate_config(const gomel_config* c) {
     if (!c) return GOMEL_ERR_NULL;
     if (c->num_mels <= 0 || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
     if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
-    if (c->resolut != 1024 && c->resolut != 2048 && c->resolut != 4096) return GOMEL_ERR_UNSUPPORTED_N;
+    if (!gomel_supported_n(c->resolut)) return GOMEL_ERR_UNSUPPORTED_N;
     return GOMEL_OK;
 }
 
@@ -171,7 +171,8 @@ template <class V> static void fill_twiddles(int N, int R1, int R2, std::vector<
 
 static int upload_tables(gomel_handle* h) {
     const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
-    const int R1 = (N == 1024) ? 8 : 16, R2 = (N == 4096) ? 16 : 8;
+    int R1 = 0, R2 = 0;
+    GOMEL_DISPATCH_N(N, R1 = Geo<NN>::R1; R2 = Geo<NN>::R2);
     std::vector<v2f> tw1, tw2, wn;
     std::vector<v2d> tw1d, tw2d, wnd;
     fill_twiddles<v2f>(N, R1, R2, tw1, tw2, wn);
@@ -398,9 +399,7 @@ template <int N> static void launch_fused_n(gomel_batch* b, int cur, int sh) {
 }
 static void launch_fused(gomel_batch* b, int cur) {
     const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
-    if (N == 4096) launch_fused_n<4096>(b, cur, sh);
-    else if (N == 2048) launch_fused_n<2048>(b, cur, sh);
-    else launch_fused_n<1024>(b, cur, sh);
+    GOMEL_DISPATCH_N(N, launch_fused_n<NN>(b, cur, sh));
 }
 
 template <int N> static void launch_frames(gomel_batch* b, const float* x) {
@@ -432,12 +431,10 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
-            const int64_t blocks = (b->total_frames + (128 / (N / 32)) - 1) / (128 / (N / 32));
+            const int64_t spb = 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
             for (int it = 0; it < I; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
-                if (N == 4096) hipLaunchKernelGGL(k_gl_frames_d<4096>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt);
-                else if (N == 2048) hipLaunchKernelGGL(k_gl_frames_d<2048>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt);
-                else hipLaunchKernelGGL(k_gl_frames_d<1024>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt);
+                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_frames_d<NN>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt));
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
                 hipLaunchKernelGGL(k_ola<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
                 curd ^= 1;
@@ -454,9 +451,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         for (int it = 0; it < I; it++) {
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
             if (b->fast) launch_fused(b, cur);
-            else if (N == 4096) launch_frames<4096>(b, b->d_x[cur]);
-            else if (N == 2048) launch_frames<2048>(b, b->d_x[cur]);
-            else launch_frames<1024>(b, b->d_x[cur]);
+            else { GOMEL_DISPATCH_N(N, launch_frames<NN>(b, b->d_x[cur])); }
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
             if (!b->fast) hipLaunchKernelGGL(k_ola<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
             cur ^= 1;
@@ -507,9 +502,7 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     int rc = GOMEL_OK;
     if (hipMemcpyAsync(d_in, in, in_b, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        if (N == 4096) launch_fft<4096>(h, inverse, d_in, d_out, (int64_t)n_frames);
-        else if (N == 2048) launch_fft<2048>(h, inverse, d_in, d_out, (int64_t)n_frames);
-        else launch_fft<1024>(h, inverse, d_in, d_out, (int64_t)n_frames);
+        GOMEL_DISPATCH_N(N, launch_fft<NN>(h, inverse, d_in, d_out, (int64_t)n_frames));
         if (hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
             g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
         }
@@ -534,7 +527,7 @@ const char* gomel_strerror(int s) {
     switch (s) {
         case GOMEL_OK: return "ok";
         case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax)";
-        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut must be 1024, 2048 or 4096";
+        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut must be 256, 512, 1024, 2048 or 4096";
         case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
         case GOMEL_ERR_EMPTY: return "empty input";
         case GOMEL_ERR_TABLE_RANGE: return "mel table indexes outside the band/bin range for this configuration";
@@ -922,7 +915,8 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
         if (!rc)
             for (size_t f = 0; f < F; f++) {
                 for (int k = 0; k < H; k++) {
-                    const int slot = N == 4096 ? mag_slot_index<Geo<4096>>(k) : (N == 2048 ? mag_slot_index<Geo<2048>>(k) : mag_slot_index<Geo<1024>>(k));
+                    int slot = 0;
+                    GOMEL_DISPATCH_N(N, slot = mag_slot_index<Geo<NN>>(k));
                     mag_out[f * (H + 1) + k] = mg[f * H + slot];
                 }
                 mag_out[f * (H + 1) + H] = ny[f];
@@ -961,9 +955,8 @@ int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pair
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
                 hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        if (N == 4096) hipLaunchKernelGGL(k_stft_mag<4096>, dim3((unsigned)((F + 0) / 1)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt);
-        else if (N == 2048) hipLaunchKernelGGL(k_stft_mag<2048>, dim3((unsigned)((F + 1) / 2)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt);
-        else hipLaunchKernelGGL(k_stft_mag<1024>, dim3((unsigned)((F + 3) / 4)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt);
+        GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
+                              hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((F + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt); });
         hipLaunchKernelGGL(k_domel_log, dim3((unsigned)F), dim3(256), 0, h->stream, d_smag, h->dt.dom, d_out, K, H);
         if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
@@ -1009,9 +1002,8 @@ int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
                 hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        if (N == 4096) hipLaunchKernelGGL(k_phase_stft<4096>, dim3((unsigned)F), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt);
-        else if (N == 2048) hipLaunchKernelGGL(k_phase_stft<2048>, dim3((unsigned)((F + 1) / 2)), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt);
-        else hipLaunchKernelGGL(k_phase_stft<1024>, dim3((unsigned)((F + 3) / 4)), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt);
+        GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
+                              hipLaunchKernelGGL(k_phase_stft<NN>, dim3((unsigned)((F + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_out, (int64_t)F, hop, nf, h->dt); });
         if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     }
@@ -1047,9 +1039,8 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
         h->pool.alloc((void**)&d_out, L * 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && hipMemcpyAsync(d_in, pairs, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        if (N == 4096) hipLaunchKernelGGL(k_phase_istft<4096>, dim3((unsigned)F), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
-        else if (N == 2048) hipLaunchKernelGGL(k_phase_istft<2048>, dim3((unsigned)((F + 1) / 2)), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
-        else hipLaunchKernelGGL(k_phase_istft<1024>, dim3((unsigned)((F + 3) / 4)), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt);
+        GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
+                              hipLaunchKernelGGL(k_phase_istft<NN>, dim3((unsigned)((F + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_in, d_yw, (int64_t)F, num_freqs, h->dt); });
         const unsigned g = (unsigned)std::min<size_t>((L + 255) / 256, 65536);
         hipLaunchKernelGGL(k_phase_ola, dim3(g), dim3(256), 0, h->stream, d_yw, d_out, (int64_t)L, (int)F, N, hop, h->dt.windowd, mx * 0.5, volume_boost);
         if (hipMemcpyAsync(out, d_out, L * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {

@@ -33,7 +33,7 @@ extern "C" {
 typedef enum gomel_status {
     GOMEL_OK = 0,
     GOMEL_ERR_BAD_CONFIG = 1,     /* NumMels/Window/Resolut <= 0, TuneMul == 0, fmax+fmin <= 0 ...                 */
-    GOMEL_ERR_UNSUPPORTED_N = 2,  /* Resolut not in {1024, 2048, 4096} (reference: any N, Bluestein if not 2^k)  */
+    GOMEL_ERR_UNSUPPORTED_N = 2,  /* Resolut not in {256,...,4096 powers of 2} (reference: any N, Bluestein) */
     GOMEL_ERR_BAD_LENGTH = 3,     /* n_pairs % NumMels != 0 (reference: index panic, mel/impl.go:366)             */
     GOMEL_ERR_EMPTY = 4,          /* zero frames (reference: index panic at mel/mel.go:78)                        */
     GOMEL_ERR_TABLE_RANGE = 5,    /* undomel/domel table indexes past the band/bin slice (reference: panic)       */

@@ -15,6 +15,8 @@ GEOMS = {
     "T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096),   # cmd/towav/main.go:30-36
     "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),      # BASELINE config 4
     "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048),     # NewMel defaults mel/mel.go:30-41
+    "Q": dict(NumMels=64, MelFmax=8000.0, Window=160, Resolut=512),       # 16 kHz speech front end: 32 ms frames, 10 ms hop
+    "E": dict(NumMels=40, MelFmax=4000.0, Window=80, Resolut=256),        # 8 kHz telephony: 32 ms frames, 10 ms hop
 }
 
 
@@ -37,7 +39,7 @@ def ocfg(oracle, geom, iters, **kw):
     return oracle.MelConfig(**dict(GEOMS[geom], GriffinLimIterations=iters, **kw))
 
 
-@pytest.mark.parametrize("geom", ["T", "S", "D"])
+@pytest.mark.parametrize("geom", ["T", "S", "D", "Q", "E"])
 def test_rfft_irfft_hooks(geom):
     m = make_mel(geom, 1)
     e = m.engine()
@@ -56,7 +58,7 @@ def test_rfft_irfft_hooks(geom):
     assert np.max(np.abs(back - frames)) < 5e-6 * max(1.0, float(np.abs(frames).max()))
 
 
-@pytest.mark.parametrize("geom", ["T", "S", "D"])
+@pytest.mark.parametrize("geom", ["T", "S", "D", "Q", "E"])
 def test_target_magnitudes(oracle, geom):
     m = make_mel(geom, 1, TuneMul=1.25, TuneAdd=0.01)
     cfg = ocfg(oracle, geom, 1, TuneMul=1.25, TuneAdd=0.01)
@@ -68,7 +70,7 @@ def test_target_magnitudes(oracle, geom):
 
 
 @pytest.mark.parametrize("path", [2, 1])
-@pytest.mark.parametrize("geom,frames", [("T", 4), ("T", 9), ("S", 8), ("S", 3), ("D", 6), ("T", 1), ("T", 40), ("S", 70), ("D", 33)])
+@pytest.mark.parametrize("geom,frames", [("T", 4), ("T", 9), ("S", 8), ("S", 3), ("D", 6), ("T", 1), ("T", 40), ("S", 70), ("D", 33), ("Q", 5), ("Q", 90), ("Q", 1), ("E", 7), ("E", 130), ("E", 1)])
 @pytest.mark.parametrize("iters", [0, 1, 2, 60])
 def test_from_mel_matches_oracle(oracle, geom, frames, iters, path):
     if iters == 60 and frames > 40:
@@ -231,14 +233,14 @@ def test_extreme_magnitudes_and_negative_tune(oracle):
     assert rms(m.FromMel(mel.copy(), x0=x0) - oracle.from_mel(cfg, mel.copy(), x0)) < RMS_TOL
 
 
-@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
 @pytest.mark.parametrize("SH", [1, 2, 4, 5, 8])
 def test_every_fused_instantiation(oracle, N, SH):
-    """k_gl_fused<N, SH> for all 15 instantiated (N, hop = SH*N/16) pairs, on a ragged batch so that streams sharing a
+    """k_gl_fused<N, SH> for all 25 instantiated (N, hop = SH*N/16) pairs, on a ragged batch so that streams sharing a
     workgroup walk segments of different lengths, against the oracle and against the generic kernels."""
     import gomel_amd
     hop = SH * N // 16
-    K = {1024: 80, 2048: 160, 4096: 192}[N]
+    K = {256: 40, 512: 64, 1024: 80, 2048: 160, 4096: 192}[N]
     kw = dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=3)
     cfg = oracle.MelConfig(**kw)
     fr = [1, 2, 3, 5, 9, 17, 33, 4, 7, 21]
@@ -275,7 +277,7 @@ def test_automatic_path_choice(oracle):
         assert rms(out - oracle.from_mel(cfg, mels[0].copy(), oracle.x0_splitmix(0, len(out)))) < RMS_TOL
 
 
-@pytest.mark.parametrize("geom,frames,iters", [("T", 9, 60), ("S", 24, 60), ("D", 12, 20), ("T", 3, 2)])
+@pytest.mark.parametrize("geom,frames,iters", [("T", 9, 60), ("S", 24, 60), ("D", 12, 20), ("T", 3, 2), ("Q", 30, 60), ("E", 50, 60)])
 def test_precise_mode_is_the_fp64_algorithm(oracle, geom, frames, iters):
     """gomel_set_precision(64): the generic kernels in fp64 end to end.  Against the fp64 oracle this is agreement between two
     implementations of the same arithmetic (different FFT factorisation, different summation order): ~1e-13."""
@@ -299,7 +301,7 @@ def test_mel_tables_fuzz_against_oracle(oracle):
     rng = np.random.default_rng(2024)
     ran = refused = 0
     for trial in range(60):
-        N = int(rng.choice([1024, 2048, 4096]))
+        N = int(rng.choice([256, 512, 1024, 2048, 4096]))
         K = int(rng.integers(6, 400))
         fmin = float(rng.choice([0.0, 0.0, rng.uniform(0, 400)]))
         fmax = float(rng.uniform(1500, 26000))
@@ -336,7 +338,7 @@ def test_from_mel_fuzz_configs(oracle):
     import gomel_amd
     rng = np.random.default_rng(5150)
     for trial in range(40):
-        N = int(rng.choice([1024, 2048, 4096]))
+        N = int(rng.choice([256, 512, 1024, 2048, 4096]))
         hop = int(rng.choice([N // 16, N // 4, 5 * N // 16, N // 2, N, int(rng.integers(8, N)), 2 * int(rng.integers(8, N // 2)) + 1]))
         K = int(rng.integers(8, 256))
         I = int(rng.integers(0, 4))

@@ -43,7 +43,7 @@ def test_oracle_round_trip_and_normalisation(oracle, po):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,hop,nf", [(4096, 1280, 768), (4096, 1280, 2048), (2048, 256, 836), (1024, 256, 512), (4096, 1280, 1), (2048, 275, 700), (1024, 441, 300)])
+@pytest.mark.parametrize("N,hop,nf", [(4096, 1280, 768), (4096, 1280, 2048), (2048, 256, 836), (1024, 256, 512), (4096, 1280, 1), (2048, 275, 700), (1024, 441, 300), (512, 128, 200), (512, 160, 256), (256, 64, 100)])
 def test_to_phase_from_phase_match_oracle(oracle, po, N, hop, nf):
     import gomel_amd
     m = gomel_amd.NewPhase()

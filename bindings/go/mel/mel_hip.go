@@ -18,9 +18,12 @@ import "C"
 import (
 	"errors"
 	"math"
+	"math/cmplx"
 	"math/rand"
 	"sync"
 	"unsafe"
+
+	"github.com/r9y9/gossp/stft"
 )
 
 // Mel represents the configuration for generating mel spectrograms (field for field the reference's struct).
@@ -131,6 +134,44 @@ func (m *Mel) FromMel(ospectrum [][2]float64) ([]float64, error) {
 		ospectrum[i][1] = math.Exp(ospectrum[i][1])
 	}
 	return out[:int(got)], statusErr(rc)
+}
+
+// ISTFT is the Griffin-Lim loop itself (mel/mel.go:76-139).  Of `spectrogram` the reference reads only the magnitudes of
+// bins 0..frameLen/2 (phases are re-estimated, the upper half is conjugate-filled), so those are what crosses the boundary;
+// s.Window is injected as the analysis/synthesis window.  The reference also leaves its last phase estimate in the caller's
+// spectrogram; this shim does not.
+func ISTFT(s *stft.STFT, spectrogram [][]complex128, numIterations int) []float64 {
+	numFrames, frameLen := len(spectrogram), len(spectrogram[0]) // panics on an empty spectrogram, as the reference does
+	var c C.gomel_config
+	C.gomel_default_config(&c)
+	c.resolut, c.window = C.int32_t(frameLen), C.int32_t(s.FrameShift)
+	var h *C.gomel_handle
+	if rc := C.gomel_create(&c, &h); rc != C.GOMEL_OK {
+		panic(statusErr(rc))
+	}
+	defer C.gomel_destroy(h)
+	if rc := C.gomel_set_window(h, (*C.double)(unsafe.Pointer(&s.Window[0])), C.size_t(len(s.Window))); rc != C.GOMEL_OK {
+		panic(statusErr(rc))
+	}
+	half := frameLen/2 + 1
+	mags := make([]float64, numFrames*half)
+	for i := range spectrogram {
+		for j := 0; j < half; j++ {
+			mags[i*half+j] = cmplx.Abs(spectrogram[i][j])
+		}
+	}
+	L := frameLen + (numFrames-1)*s.FrameShift
+	x0 := make([]float64, L)
+	for i := range x0 {
+		x0[i] = rand.Float64()
+	}
+	out := make([]float64, L)
+	var got C.size_t
+	if rc := C.gomel_istft(h, (*C.double)(unsafe.Pointer(&mags[0])), C.size_t(numFrames), C.int32_t(numIterations),
+		(*C.double)(unsafe.Pointer(&x0[0])), 0, (*C.double)(unsafe.Pointer(&out[0])), C.size_t(L), &got); rc != C.GOMEL_OK {
+		panic(statusErr(rc))
+	}
+	return out[:int(got)]
 }
 
 // Close releases the device handle (no counterpart in the reference, which holds no resources).

@@ -42,6 +42,8 @@ SYMBOLS = {
     "gomel_out_len": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
     "gomel_from_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_uint64, c_double_p,
                                       ctypes.c_size_t, c_size_p]),
+    "gomel_istft": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, ctypes.c_int32, c_double_p, ctypes.c_uint64, c_double_p,
+                                   ctypes.c_size_t, c_size_p]),
     "gomel_from_mel_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p,
                                             ctypes.POINTER(c_double_p), c_u64_p, ctypes.POINTER(c_double_p), c_size_p]),
     "gomel_batch_create": (ctypes.c_int, [_vp, ctypes.c_size_t, c_size_p, ctypes.POINTER(_vp)]),

@@ -129,6 +129,24 @@ static void launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const double
     GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_mel_to_mag<NN, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n));
 }
 
+// Linear magnitudes given directly (gomel_istft = the reference's exported ISTFT, mel/mel.go:76-139, which reads only
+// |spectrogram[i][j]|, j <= N/2): in[f][N/2+1] doubles -> the same lane-slot rows / Nyquist array as k_mel_to_mag, 1/N folded in.
+template <int N, class MagT>
+__global__ __launch_bounds__(256) void k_mag_direct(const double* __restrict__ in, MagT* __restrict__ mag, MagT* __restrict__ nyq,
+                                                    double inv_n) {
+    constexpr int H = N / 2;
+    const int64_t f = blockIdx.x;
+    const double* m = in + f * (H + 1);
+    for (int k = threadIdx.x; k < H; k += 256) mag[f * H + mag_slot_index<Geo<N>>(k)] = (MagT)(fabs(m[k]) * inv_n);
+    if (threadIdx.x == 0) nyq[f] = (MagT)(fabs(m[H]) * inv_n);
+}
+
+template <class MagT>
+static void launch_mag_direct(int N, int64_t frames, hipStream_t s, const double* in, MagT* mag, MagT* nyq) {
+    const double inv_n = 1.0 / (double)N;
+    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_mag_direct<NN, MagT>), dim3((unsigned)frames), dim3(256), 0, s, in, mag, nyq, inv_n));
+}
+
 // =============================================================================================== K3: initial signal
 GL_DEV double splitmix_u01(uint64_t seed, uint64_t i) {
     uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;

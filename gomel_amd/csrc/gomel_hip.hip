@@ -307,6 +307,8 @@ struct gomel_batch {
     int64_t total_frames = 0, total_len = 0, total_pairs = 0, max_len = 0;
     bool any_x0 = false, uploaded = false;
     int fast = 0;
+    int direct = 0;            // gomel_istft: d_mel holds linear magnitudes [total_frames][N/2+1] instead of log-mel pairs
+    int iters = -1;            // >= 0: overrides cfg.griffin_lim_iterations (ISTFT's numIterations argument)
     // device
     double* d_mel = nullptr;   // [total_pairs][2]
     double* d_x0 = nullptr;    // [total_len] (only when some x0 is given)
@@ -413,7 +415,7 @@ template <int N> static void launch_frames(gomel_batch* b, const float* x) {
 static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     gomel_handle* h = b->h;
     const gomel_config& c = h->cfg;
-    const int N = c.resolut, H = N / 2, K = c.num_mels, I = c.griffin_lim_iterations;
+    const int N = c.resolut, H = N / 2, K = c.num_mels, I = b->iters >= 0 ? b->iters : c.griffin_lim_iterations;
     hipStream_t s = h->stream;
     if (!b->uploaded) return GOMEL_ERR_NULL;
     if (tm) {
@@ -427,7 +429,8 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
-            launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
+            if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, b->d_mel, b->d_magd, b->d_nyqd);
+            else launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
             hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
@@ -442,7 +445,8 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
             HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
         } else {
-        launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
+        if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, b->d_mel, b->d_mag, b->d_nyq);
+        else launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
         hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
@@ -646,12 +650,14 @@ int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.g
     return gomel_pad_len(orig, window) == padded ? 1 : 0;
 }
 
-static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+// One plan for both kinds of input: log-mel pairs (n_pairs[u] = frames * NumMels) or, for gomel_istft, linear magnitudes
+// (`direct`: n_pairs[u] = frames, rows of N/2+1 doubles).  `iters` >= 0 overrides the configured iteration count.
+static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pairs, int direct, int iters, gomel_batch** out) {
     if (!h || !n_pairs || !out) return GOMEL_ERR_NULL;
     *out = nullptr;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
     const gomel_config& c = h->cfg;
-    const int N = c.resolut, K = c.num_mels, hop = c.window;
+    const int N = c.resolut, K = direct ? 1 : c.num_mels, hop = c.window;
     for (size_t u = 0; u < n_utt; u++) {
         if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
         if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
@@ -661,7 +667,7 @@ static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_p
     gomel_batch* b = new (std::nothrow) gomel_batch();
     if (!b) return GOMEL_ERR_NO_MEMORY;
     BatchGuard guard{b};
-    b->h = h; b->n_utt = n_utt;
+    b->h = h; b->n_utt = n_utt; b->direct = direct; b->iters = iters;
     b->utts.resize(n_utt); b->n_pairs.assign(n_pairs, n_pairs + n_utt);
     for (size_t u = 0; u < n_utt; u++) {
         UttDesc& d = b->utts[u];
@@ -676,10 +682,10 @@ static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_p
     // to fill the chip; one short utterance (<= 512 frames, measured crossover) is faster with every frame in parallel.
     b->precise = h->precision == 64 ? 1 : 0;
     b->fast = (!b->precise && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames > 512)) ? 1 : 0;
-    const int I = c.griffin_lim_iterations;
+    const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
-    alloc((void**)&b->d_mel, (size_t)b->total_pairs * 16);
+    alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * (size_t)(N / 2 + 1) * 8 : (size_t)b->total_pairs * 16);
     alloc((void**)&b->d_out, (size_t)b->total_len * 8);
     alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
     if (I > 0 && b->precise) {
@@ -719,6 +725,10 @@ static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_p
     return GOMEL_OK;
 }
 
+static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+    return batch_create_common(h, n_utt, n_pairs, 0, -1, out);
+}
+
 // H2D of log-mel and x0 on the compute stream (asynchronous when `pins` already covers the host buffers).
 static int batch_upload_impl(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds, bool pin_here, bool wait) {
     gomel_handle* h = b->h;
@@ -733,12 +743,13 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
     PinnedScope pins;
     if (pin_here)
         for (size_t u = 0; u < b->n_utt; u++) {
-            pins.pin(mel[u], b->n_pairs[u] * 16);
+            pins.pin(mel[u], b->n_pairs[u] * (b->direct ? (size_t)(h->cfg.resolut / 2 + 1) * 8 : 16));
             if (b->utts[u].has_x0) pins.pin(x0[u], (size_t)b->utts[u].len * 8);
         }
     int64_t poff = 0;
     for (size_t u = 0; u < b->n_utt; u++) {
-        HIPCHK(hipMemcpyAsync(b->d_mel + poff * 2, mel[u], b->n_pairs[u] * 16, hipMemcpyDefault, h->stream));
+        const size_t row = b->direct ? (size_t)(h->cfg.resolut / 2 + 1) : 2;   // doubles per input unit (magnitude row / pair)
+        HIPCHK(hipMemcpyAsync(b->d_mel + poff * (int64_t)row, mel[u], b->n_pairs[u] * row * 8, hipMemcpyDefault, h->stream));
         poff += (int64_t)b->n_pairs[u];
         if (b->utts[u].has_x0)
             HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->stream));
@@ -886,6 +897,32 @@ int gomel_from_mel(gomel_handle* h, const double* mel, size_t n_pairs, const dou
     const double* x0s[1] = {x0};
     double* outs[1] = {out};
     int rc = gomel_from_mel_batch(h, 1, mels, &n_pairs, x0s, &seed, outs, &out_cap);
+    if (!rc && out_len) *out_len = L;
+    return rc;
+}
+
+// ISTFT as an entry point of its own: Griffin-Lim from linear magnitudes, `iterations` = numIterations.
+static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,
+                         double* out, size_t out_cap, size_t* out_len) {
+    if (!h || !mags || !out) return GOMEL_ERR_NULL;
+    if (n_frames == 0) return GOMEL_ERR_EMPTY;
+    if (iterations < 0) return GOMEL_ERR_BAD_CONFIG;
+    const size_t L = (size_t)h->cfg.resolut + (n_frames - 1) * (size_t)h->cfg.window;   // mel/mel.go:80
+    if (out_cap < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    gomel_batch* b = nullptr;
+    int rc = batch_create_common(h, 1, &n_frames, 1, iterations, &b);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (hipSetDevice(h->device) != hipSuccess) rc = GOMEL_ERR_HIP;
+        const double* ins[1] = {mags};
+        const double* x0s[1] = {x0};
+        if (!rc) rc = batch_upload_impl(b, ins, x0s, &seed, true, true);
+        if (!rc) rc = batch_run_impl(b, nullptr);
+    }
+    double* outs[1] = {out};
+    if (!rc) rc = gomel_batch_download(b, outs, &out_cap);
+    gomel_batch_destroy(b);
     if (!rc && out_len) *out_len = L;
     return rc;
 }
@@ -1083,6 +1120,10 @@ int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, 
 int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out, size_t out_cap,
                      size_t* out_len) {
     GOMEL_TRY return from_phase_guarded(h, num_freqs, volume_boost, pairs, n_pairs, out, out_cap, out_len); GOMEL_CATCH
+}
+int gomel_istft(gomel_handle* h, const double* mags, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed, double* out,
+                size_t out_cap, size_t* out_len) {
+    GOMEL_TRY return istft_guarded(h, mags, n_frames, iterations, x0, seed, out, out_cap, out_len); GOMEL_CATCH
 }
 
 }  // extern "C"

@@ -114,6 +114,26 @@ class Engine:
                                out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_from_mel")
         return out[:got.value]
 
+    def istft(self, magnitudes, iterations, x0=None, seed=0):
+        """gomel_istft: Griffin-Lim from linear magnitudes [F][N/2+1] (the reference's exported ISTFT, mel/mel.go:76-139)."""
+        m = np.ascontiguousarray(magnitudes, dtype=np.float64)
+        H1 = self.cfg.resolut // 2 + 1
+        if m.ndim != 2 or m.shape[1] != H1:
+            raise ValueError("magnitudes must be [frames, %d]" % H1)
+        F = m.shape[0]
+        n = self.cfg.resolut + (F - 1) * self.cfg.window if F else 0
+        out = np.empty(max(n, 1), dtype=np.float64)
+        x0p = None
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float64)
+            if x0.shape != (n,):
+                raise ValueError("x0 must have length %d" % n)
+            x0p = x0.ctypes.data_as(c_double_p)
+        got = ctypes.c_size_t(0)
+        check(_lib.lib().gomel_istft(self._h, m.ctypes.data_as(c_double_p), F, int(iterations), x0p, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                     out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_istft")
+        return out[:got.value]
+
     def from_mel_batch(self, mels, x0s=None, seeds=None, outs=None):
         """gomel_from_mel_batch: host buffers in, host buffers out (chunked, copy/compute overlapped inside the library).
         `outs` may be preallocated float64 arrays (caller-owned buffers); otherwise fresh arrays are returned."""
@@ -355,6 +375,34 @@ class Mel:
             self.SampleRate = int(samplerate)
         codec.dumpwav(outputFile, owave, self.SampleRate)  # the reference drops this error (mel.go:235)
         return None
+
+
+def ISTFT(s, spectrogram, numIterations, x0=None, seed=None, device=-1):
+    """`func ISTFT(s *stft.STFT, spectrogram [][]complex128, numIterations int) []float64`, mel/mel.go:76-139.
+
+    `s` is anything with the two fields of gossp's STFT the reference reads: `FrameShift` (hop) and `Window` (frameLen
+    doubles).  `spectrogram` is [F][frameLen] complex (or real magnitudes); as in the reference only |spectrogram[f][j]|,
+    j <= frameLen/2, matter.  The initial signal is `x0`, or the documented SplitMix64 stream of `seed`, or (neither given)
+    Python's `random`, where the reference draws from math/rand.  Unlike the reference the caller's spectrogram is left
+    untouched (the reference overwrites it with the last phase estimate)."""
+    spec = np.asarray(spectrogram)
+    if spec.ndim != 2 or spec.shape[0] == 0:
+        raise GomelError(4, "ISTFT")          # the reference panics on spectrogram[0] (mel/mel.go:78)
+    N = spec.shape[1]
+    window = np.ascontiguousarray(s.Window, dtype=np.float64)
+    if window.shape != (N,):
+        raise ValueError("len(s.Window) must equal the frame length %d" % N)
+    cfg = GomelConfig()
+    check(_lib.lib().gomel_default_config(ctypes.byref(cfg)), "gomel_default_config")
+    cfg.resolut, cfg.window, cfg.device = N, int(s.FrameShift), int(device)
+    e = Engine(cfg)
+    try:
+        e.set_window(window)
+        if x0 is None and seed is None:
+            seed = random.getrandbits(64)
+        return e.istft(np.abs(spec[:, :N // 2 + 1]), numIterations, x0=x0, seed=seed or 0)
+    finally:
+        e.close()
 
 
 def NewMel():

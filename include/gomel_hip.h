@@ -107,6 +107,15 @@ size_t gomel_out_len(const gomel_config* cfg, size_t n_pairs);
 int gomel_from_mel(gomel_handle* h, const double* mel_pairs, size_t n_pairs, const double* x0, uint64_t seed,
                    double* out, size_t out_cap, size_t* out_len);
 
+/* ISTFT(s, spectrogram, numIterations), mel/mel.go:76-139 -- the Griffin-Lim loop itself, exported by the reference.  Of its
+ * complex [F][N] argument it reads only |spectrogram[f][j]| for j <= N/2 (phases are re-estimated every iteration and the upper
+ * half is conjugate-filled, mel.go:98-108), so the boundary takes those magnitudes: [n_frames][N/2+1] doubles (host or device).
+ * Window and hop come from the handle (gomel_set_window injects s.Window); `iterations` = numIterations >= 0 replaces the
+ * handle's GriffinLimIterations for this call.  x0 / seed / out as for gomel_from_mel.  The reference also leaves the updated
+ * phases in the caller's spectrogram; that side effect is not reproduced. */
+int gomel_istft(gomel_handle* h, const double* magnitudes, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,
+                double* out, size_t out_cap, size_t* out_len);
+
 /* Many independent FromMel calls in one go (utterances are independent: mel/mel.go:142-152 keeps no state).
  * x0 may be NULL, and so may any x0[u]; seeds may be NULL (then seed = u). */
 int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel_pairs, const size_t* n_pairs,

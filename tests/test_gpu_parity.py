@@ -361,3 +361,30 @@ def test_from_mel_fuzz_configs(oracle):
         if np.all(np.isfinite(want)):
             assert rms(got - want) < RMS_TOL * max(1.0, rms(want)), (fields, F, rms(got - want))
         m.engine().close()
+
+
+@pytest.mark.parametrize("N,hop,F,iters", [(4096, 1280, 12, 3), (1024, 256, 40, 60), (512, 160, 9, 2), (2048, 300, 5, 1), (256, 64, 700, 2),
+                                           (1024, 256, 3, 0)])
+def test_istft_entry_matches_the_literal_loop(oracle, N, hop, F, iters):
+    """gomel_istft / gomel_amd.ISTFT against the oracle's literal restatement of mel/mel.go:76-139 fed a COMPLEX spectrogram
+    with arbitrary phases and an arbitrary (inconsistent) upper half -- the loop must ignore both."""
+    import gomel_amd
+    from types import SimpleNamespace
+    rng = np.random.default_rng(N + F)
+    mag = rng.uniform(0.0, 2.0, size=(F, N))
+    spec = mag * np.exp(1j * rng.uniform(-np.pi, np.pi, size=(F, N)))
+    window = oracle.hann(N) if F % 2 else rng.uniform(0.1, 1.0, size=N)          # injected s.Window, not only Hann
+    L = N + (F - 1) * hop
+    x0 = oracle.x0_splitmix(3, L)
+    want = oracle.istft_griffin_lim(window, hop, spec.copy(), iters, x0)
+    s = SimpleNamespace(FrameShift=hop, Window=window)
+    keep = spec.copy()
+    got = gomel_amd.ISTFT(s, spec, iters, x0=x0)
+    assert np.array_equal(spec, keep)                                            # caller's spectrogram untouched (documented)
+    assert got.shape == want.shape
+    assert rms(got - want) < RMS_TOL * max(1.0, rms(want)), rms(got - want)
+    assert rms(gomel_amd.ISTFT(s, spec, iters, seed=3) - want) < RMS_TOL * max(1.0, rms(want))   # same stream through the seed route
+    if iters == 0:
+        assert np.array_equal(got, x0)                                           # no iteration: the random init comes back
+    with pytest.raises(gomel_amd.GomelError):
+        gomel_amd.ISTFT(s, spec[:0], iters)

@@ -415,7 +415,7 @@ template <int N> static void launch_frames(gomel_batch* b, const float* x) {
 static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     gomel_handle* h = b->h;
     const gomel_config& c = h->cfg;
-    const int N = c.resolut, H = N / 2, K = c.num_mels, I = b->iters >= 0 ? b->iters : c.griffin_lim_iterations;
+    const int N = c.resolut, K = c.num_mels, I = b->iters >= 0 ? b->iters : c.griffin_lim_iterations;
     hipStream_t s = h->stream;
     if (!b->uploaded) return GOMEL_ERR_NULL;
     if (tm) {

@@ -36,6 +36,8 @@ SYMBOLS = {
     "gomel_create_from_tables": (ctypes.c_int, [_cfg_p, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "gomel_tables_bytes": (ctypes.c_size_t, [_vp]),
     "gomel_tables_export": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "gomel_tables_bytes_for": (ctypes.c_size_t, [_cfg_p]),
+    "gomel_tables_build": (ctypes.c_int, [_cfg_p, _vp, ctypes.c_size_t]),
     "gomel_set_window": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t]),
     "gomel_get_window": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t]),
     "gomel_destroy": (ctypes.c_int, [_vp]),

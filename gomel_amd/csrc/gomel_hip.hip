@@ -141,6 +141,19 @@ static int build_mel_tables(const gomel_config& c, std::vector<BinRow>& undo, st
     return GOMEL_OK;
 }
 
+// Everything a handle derives from the configuration alone (no device involved): Hann, undomel rows, domel rows.
+static int build_host_tables(const gomel_config& c, std::vector<double>& window, std::vector<BinRow>& undo, std::vector<BinRow>& dom,
+                             int* dom_status) {
+    const int N = c.resolut;
+    window.resize(N);
+    const double arg = 2.0 * M_PI / (double)(c.hann_periodic ? N : N - 1);  // gossp window.CreateHanning
+    for (int i = 0; i < N; i++) window[i] = 0.5 - 0.5 * std::cos(arg * (double)i);
+    return build_mel_tables(c, undo, dom, dom_status);
+}
+
+static void pack_tables(const gomel_config& c, int dom_status, const std::vector<double>& window, const std::vector<BinRow>& undo,
+                        const std::vector<BinRow>& dom, void* blob);
+
 static int validate_config(const gomel_config* c) {
     if (!c) return GOMEL_ERR_NULL;
     if (c->num_mels <= 0 || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
@@ -233,10 +246,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         h->cfg.hann_periodic = th.hann_periodic;
         h->dom_status = th.dom_status;
     } else {
-        h->window.resize(N);
-        const double arg = 2.0 * M_PI / (double)(cfg->hann_periodic ? N : N - 1);  // gossp window.CreateHanning
-        for (int i = 0; i < N; i++) h->window[i] = 0.5 - 0.5 * std::cos(arg * (double)i);
-        rc = build_mel_tables(*cfg, h->undo, h->dom, &h->dom_status);
+        rc = build_host_tables(*cfg, h->window, h->undo, h->dom, &h->dom_status);
         if (rc) { delete h; return rc; }
     }
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -515,6 +525,16 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     return rc;
 }
 
+static void pack_tables(const gomel_config& c, int dom_status, const std::vector<double>& window, const std::vector<BinRow>& undo,
+                        const std::vector<BinRow>& dom, void* blob) {
+    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, c.resolut, c.window, c.num_mels, c.hann_periodic, dom_status, 0, c.mel_fmin, c.mel_fmax};
+    char* p = (char*)blob;
+    memcpy(p, &th, sizeof th); p += sizeof th;
+    memcpy(p, window.data(), window.size() * 8); p += window.size() * 8;
+    memcpy(p, undo.data(), undo.size() * sizeof(BinRow)); p += undo.size() * sizeof(BinRow);
+    memcpy(p, dom.data(), dom.size() * sizeof(BinRow));
+}
+
 // =============================================================================================== C ABI
 extern "C" {
 
@@ -568,14 +588,29 @@ size_t gomel_tables_bytes(const gomel_handle* h) {
 int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap) {
     if (!h || !blob) return GOMEL_ERR_NULL;
     if (cap < gomel_tables_bytes(h)) return GOMEL_ERR_BUFFER_TOO_SMALL;
-    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, h->cfg.resolut, h->cfg.window, h->cfg.num_mels, h->cfg.hann_periodic, h->dom_status, 0,
-                   h->cfg.mel_fmin, h->cfg.mel_fmax};
-    char* p = (char*)blob;
-    memcpy(p, &th, sizeof th); p += sizeof th;
-    memcpy(p, h->window.data(), h->window.size() * 8); p += h->window.size() * 8;
-    memcpy(p, h->undo.data(), h->undo.size() * sizeof(BinRow)); p += h->undo.size() * sizeof(BinRow);
-    memcpy(p, h->dom.data(), h->dom.size() * sizeof(BinRow));
+    pack_tables(h->cfg, h->dom_status, h->window, h->undo, h->dom, blob);
     return GOMEL_OK;
+}
+
+size_t gomel_tables_bytes_for(const gomel_config* c) {
+    if (validate_config(c) != GOMEL_OK) return 0;
+    return sizeof(TableHeader) + (size_t)c->resolut * 8 + ((size_t)c->resolut / 2 + c->num_mels) * sizeof(BinRow);
+}
+
+int gomel_tables_build(const gomel_config* cfg, void* blob, size_t cap) {
+    if (!cfg || !blob) return GOMEL_ERR_NULL;
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+    if (cap < gomel_tables_bytes_for(cfg)) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    GOMEL_TRY
+    std::vector<double> window;
+    std::vector<BinRow> undo, dom;
+    int dom_status = GOMEL_OK;
+    rc = build_host_tables(*cfg, window, undo, dom, &dom_status);
+    if (rc) return rc;
+    pack_tables(*cfg, dom_status, window, undo, dom, blob);
+    return GOMEL_OK;
+    GOMEL_CATCH
 }
 
 static int set_window_guarded(gomel_handle* h, const double* w, size_t n) {

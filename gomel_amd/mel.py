@@ -377,6 +377,16 @@ class Mel:
         return None
 
 
+def build_tables(cfg):
+    """gomel_tables_build: the table blob (Hann, undomel rows, domel rows) from a configuration, on the host alone -- no GPU
+    is touched.  The same bytes `Engine.export_tables()` returns for a handle of that configuration."""
+    L = _lib.lib()
+    n = L.gomel_tables_bytes_for(ctypes.byref(cfg))
+    buf = ctypes.create_string_buffer(max(n, 1))
+    check(L.gomel_tables_build(ctypes.byref(cfg), buf, n), "gomel_tables_build")
+    return bytes(buf.raw[:n])
+
+
 def ISTFT(s, spectrogram, numIterations, x0=None, seed=None, device=-1):
     """`func ISTFT(s *stft.STFT, spectrogram [][]complex128, numIterations int) []float64`, mel/mel.go:76-139.
 

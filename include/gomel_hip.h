@@ -87,6 +87,11 @@ int gomel_create(const gomel_config* cfg, gomel_handle** out);
 int gomel_create_from_tables(const gomel_config* cfg, const void* blob, size_t blob_bytes, gomel_handle** out);
 size_t gomel_tables_bytes(const gomel_handle* h);
 int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap);
+/* The same blob straight from a configuration, on the host alone (no device is touched): what rank 0 can build before any
+ * GPU work, and what lets the table logic (undomel / domel index math, mel/impl.go:311-322,348-359; gossp's Hann) be checked
+ * on a machine without a GPU.  gomel_tables_bytes_for returns 0 for an invalid configuration. */
+size_t gomel_tables_bytes_for(const gomel_config* cfg);
+int gomel_tables_build(const gomel_config* cfg, void* blob, size_t cap);
 
 /* Inject the analysis/synthesis window (s.Window, mel/mel.go:92,120): n must equal Resolut. */
 int gomel_set_window(gomel_handle* h, const double* window, size_t n);

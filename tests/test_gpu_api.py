@@ -102,6 +102,7 @@ def test_tables_blob_handle_is_bit_identical(oracle):
     m = mel_obj(FIELDS["tts_n1024"], GriffinLimIterations=4)
     e0 = m.engine()
     blob = e0.export_tables()
+    assert blob == gomel_amd.build_tables(m._config())      # the host-only builder makes the same bytes (tests/test_tables.py checks them)
     e1 = gomel_amd.Engine(m._config(), tables=blob)
     mel = oracle.random_logmel(9, 80, seed=2)
     a = e0.from_mel(mel, seed=5)

@@ -1008,7 +1008,7 @@ size_t gomel_to_mel_pairs(const gomel_config* c, size_t n) {
     return (size_t)F * (size_t)c->num_mels;
 }
 
-int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+static int to_mel_guarded(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
     if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
     const gomel_config& c = h->cfg;
     const int N = c.resolut, H = N / 2, K = c.num_mels, hop = c.window;
@@ -1022,6 +1022,9 @@ int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pair
     HIPCHK(hipSetDevice(h->device));
     double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
+    PinnedScope pins;                      // big caller buffers: pinned for the call (pageable copies run at a tenth of the rate)
+    pins.pin(wave, n * 8);
+    pins.pin(out_pairs, pairs * 16);
     if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, F * (size_t)(H + 1) * 8) != hipSuccess ||
         h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
@@ -1055,7 +1058,7 @@ size_t gomel_phase_out_len(const gomel_config* c, int32_t num_freqs, size_t n_pa
     return (size_t)c->resolut + (n_pairs / (size_t)num_freqs - 1) * (size_t)c->window;
 }
 
-int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+static int to_phase_guarded(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
     if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
     const gomel_config& c = h->cfg;
     const int N = c.resolut, hop = c.window;
@@ -1070,6 +1073,9 @@ int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_
     HIPCHK(hipSetDevice(h->device));
     double *d_wave = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
+    PinnedScope pins;
+    pins.pin(wave, n * 8);
+    pins.pin(out_pairs, pairs * 16);
     if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
                 hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
@@ -1107,6 +1113,9 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
     HIPCHK(hipSetDevice(h->device));
     double *d_in = nullptr, *d_yw = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
+    PinnedScope pins;
+    pins.pin(pairs, n_pairs * 16);
+    pins.pin(out, L * 8);
     if (h->pool.alloc((void**)&d_in, n_pairs * 16) != hipSuccess || h->pool.alloc((void**)&d_yw, F * (size_t)N * 8) != hipSuccess ||
         h->pool.alloc((void**)&d_out, L * 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && hipMemcpyAsync(d_in, pairs, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
@@ -1159,6 +1168,12 @@ int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, co
 int gomel_istft(gomel_handle* h, const double* mags, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed, double* out,
                 size_t out_cap, size_t* out_len) {
     GOMEL_TRY return istft_guarded(h, mags, n_frames, iterations, x0, seed, out, out_cap, out_len); GOMEL_CATCH
+}
+int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+    GOMEL_TRY return to_mel_guarded(h, wave, n, out_pairs, cap_pairs, n_pairs); GOMEL_CATCH
+}
+int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+    GOMEL_TRY return to_phase_guarded(h, num_freqs, wave, n, out_pairs, cap_pairs, n_pairs); GOMEL_CATCH
 }
 
 }  // extern "C"

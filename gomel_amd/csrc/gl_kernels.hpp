@@ -166,11 +166,13 @@ struct UttDesc {  // one utterance of a batch
 };
 
 template <class OutT>
-__global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, const double* __restrict__ x0, OutT* __restrict__ x) {
-    const UttDesc u = utts[blockIdx.y];
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
-        double v = u.has_x0 ? x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
-        x[u.xoff + n] = (OutT)v;
+__global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, int n_utt, const double* __restrict__ x0, OutT* __restrict__ x) {
+    for (int iu = blockIdx.y; iu < n_utt; iu += gridDim.y) {   // grid.y is capped at 65535: batches of more utterances stride
+        const UttDesc u = utts[iu];
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+            double v = u.has_x0 ? x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
+            x[u.xoff + n] = (OutT)v;
+        }
     }
 }
 
@@ -256,16 +258,18 @@ __global__ __launch_bounds__(128) void k_gl_frames_d(const double* __restrict__ 
 
 // x'[n] = sum over the frames covering n of yw[k][n - k*hop], in frame order (mel/mel.go:115-125).
 template <class S>
-__global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, const S* __restrict__ yw, S* __restrict__ xn,
+__global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, int n_utt, const S* __restrict__ yw, S* __restrict__ xn,
                                              int N, int hop) {
-    const UttDesc u = utts[blockIdx.y];
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
-        int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
-        int64_t k1 = n / hop;
-        if (k1 > u.frames - 1) k1 = u.frames - 1;
-        S acc = 0;
-        for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
-        xn[u.xoff + n] = acc;
+    for (int iu = blockIdx.y; iu < n_utt; iu += gridDim.y) {
+        const UttDesc u = utts[iu];
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+            int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
+            int64_t k1 = n / hop;
+            if (k1 > u.frames - 1) k1 = u.frames - 1;
+            S acc = 0;
+            for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
+            xn[u.xoff + n] = acc;
+        }
     }
 }
 

@@ -432,16 +432,16 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         while ((int)b->dom_ev.size() < 2 * I) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->dom_ev.push_back(e); }
         HIPCHK(hipEventRecord(b->ev[0], s));
     }
-    const unsigned gx = (unsigned)std::min<int64_t>((b->max_len + 255) / 256, 4096);
+    const unsigned gx = (unsigned)std::min<int64_t>((b->max_len + 255) / 256, 4096), gy = (unsigned)std::min<size_t>(b->n_utt, 65535);
     if (I == 0) {
         // "I = 0 returns the random init" (mel/mel.go:85 never runs): keep it in fp64
-        hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_out);
+        hipLaunchKernelGGL(k_init_x<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_out);
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
             if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, b->d_mel, b->d_magd, b->d_nyqd);
             else launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
-            hipLaunchKernelGGL(k_init_x<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_xd[0]);
+            hipLaunchKernelGGL(k_init_x<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
             const int64_t spb = 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
@@ -449,7 +449,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_frames_d<NN>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt));
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
-                hipLaunchKernelGGL(k_ola<double>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
+                hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
                 curd ^= 1;
             }
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
@@ -457,7 +457,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, b->d_mel, b->d_mag, b->d_nyq);
         else launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
-        hipLaunchKernelGGL(k_init_x<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_x0, b->d_x[0]);
+        hipLaunchKernelGGL(k_init_x<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
         const size_t tail_bytes = b->segs.size() * (size_t)(N - c.window) * 4;
@@ -467,7 +467,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (b->fast) launch_fused(b, cur);
             else { GOMEL_DISPATCH_N(N, launch_frames<NN>(b, b->d_x[cur])); }
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
-            if (!b->fast) hipLaunchKernelGGL(k_ola<float>, dim3(gx, (unsigned)b->n_utt), dim3(256), 0, s, b->d_utts, b->d_yw, b->d_x[cur ^ 1], N, c.window);
+            if (!b->fast) hipLaunchKernelGGL(k_ola<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_yw, b->d_x[cur ^ 1], N, c.window);
             cur ^= 1;
         }
         if (tm) HIPCHK(hipEventRecord(b->ev[2], s));

@@ -352,3 +352,23 @@ def test_to_mel_tables_fuzz_against_oracle(oracle):
             ran += 1
         m.engine().close()
     assert ran >= 20, (ran, refused)
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_more_utterances_than_grid_y(oracle, path):
+    """70 000 one- and two-frame utterances in one batch: more than the 65 535 blocks grid.y can hold (the per-utterance kernels
+    stride), on the fused and on the generic kernels."""
+    import gomel_amd
+    fields = dict(NumMels=8, MelFmax=4000.0, Window=64, Resolut=256, GriffinLimIterations=2)
+    m = mel_obj(fields)
+    e = m.engine()
+    e.set_path(path)
+    n = 70000
+    base = [oracle.random_logmel(f, 8, seed=f) for f in (1, 2)]
+    mels = [base[i & 1] for i in range(n)]
+    outs = e.from_mel_batch(mels, None, list(range(n)))
+    cfg = oracle.MelConfig(**fields)
+    for u in (0, 1, 65534, 65535, 65536, n - 1):
+        want = oracle.from_mel(cfg, mels[u].copy(), oracle.x0_splitmix(u, len(outs[u])))
+        assert rms(outs[u] - want) < RMS_TOL, u
+    e.close()

@@ -368,6 +368,18 @@ static int fused_shift(const gomel_config& c) {
 }
 static bool fused_applicable(const gomel_config& c) { return fused_shift(c) != 0; }
 
+// Batch size (total frames) from which the fused kernel beats the generic pair.  A fused stream walks at least gmin =
+// ceil((16-SH)/SH) frames one after the other, so a launch never takes less than gmin frame latencies, while the generic kernels
+// run every frame in parallel: measured crossovers for gmin = 3 (scripts/cross_probe2.py, 60 iterations, one launch per
+// iteration): 1.5 k frames at N 4096, 2.5 k at 2048, 3 k at 1024, 6 k at 512, 12 k at 256; scaled with gmin.
+static int64_t fused_min_frames(const gomel_config& c) {
+    const int sh = fused_shift(c);
+    if (!sh) return INT64_MAX;
+    const int64_t base = c.resolut >= 4096 ? 1536 : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288;
+    const int gmin = (16 - sh + sh - 1) / sh;
+    return base * gmin / 3;
+}
+
 static void plan_segments(gomel_batch* b) {
     const gomel_config& c = b->h->cfg;
     const int sh = fused_shift(c), keep = 16 - sh, gmin = (keep + sh - 1) / sh;
@@ -713,10 +725,10 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         b->total_frames += d.frames; b->total_pairs += (int64_t)n_pairs[u];
         b->max_len = std::max(b->max_len, d.len);
     }
-    // Path choice: the fused kernel walks >= 3 consecutive frames per stream, which only pays once there are enough frames
-    // to fill the chip; one short utterance (<= 512 frames, measured crossover) is faster with every frame in parallel.
+    // Path choice: the fused kernel walks consecutive frames per stream, which only pays once there are enough frames to fill
+    // the chip (fused_min_frames); below that every frame in parallel (generic kernels) is faster.
     b->precise = h->precision == 64 ? 1 : 0;
-    b->fast = (!b->precise && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames > 512)) ? 1 : 0;
+    b->fast = (!b->precise && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };

@@ -42,7 +42,10 @@ template <int N_, int R1_, int R2_> struct GeoBase {
     static constexpr int B3 = C / R3;     // number of pass-3 butterflies; Z index k = b + B3*r
     static constexpr int NB1 = P / R1;    // pass-1 butterflies per lane
     static constexpr int NB2 = P / R2;    // pass-2 butterflies per lane
-    static constexpr int SA = C1 + 32 / R1;  // row stride of exchange layout A (b64 slots)
+    static constexpr int SA = C1 + 32 / R1;  // row stride of exchange layout A (b64 slots), forward: rows written whole, read by (q1, t2)
+    static constexpr int SAI = C1 + 16 / R1; // the same layout in the inverse, where the (q1, t2) access is the WRITE: ds_write_b64 is
+                                             // served in groups of 16 lanes over 32 banks (reads: 32 lanes over 64), so the 16 lanes of a
+                                             // group -- R1 values of q1 x 16/R1 of t2 -- must land on 16 different slots mod 16
     static constexpr int SB = B3 + R1;       // row stride of exchange layout B
     static constexpr int SLOTS_A = R1 * SA, SLOTS_B = R3 * SB;
     static constexpr int LDS_SLOTS = SLOTS_A > SLOTS_B ? SLOTS_A : SLOTS_B;  // v2f slots per stream
@@ -264,10 +267,31 @@ template <bool INV, int R, int S, class V> GL_DEV void dftR(V* v) {
     else { static_assert(R == 4, "radix"); dft4<INV>(v[0], v[S], v[2 * S], v[3 * S]); }
 }
 
+// ---------------------------------------------------------------------------------------------- diagnostic stamps
+// Where a frame's cycles go: a diagnostic build (-DGOMEL_STAMPS, scripts/stamp_probe.py) passes a Stamps object whose mark(k)
+// reads s_memtime (and drains the wave's LDS / scalar queue, so each phase is charged with its own LDS round trips) and adds the
+// cycles since the previous mark to slot k.  The product build passes NoStamps: every mark is empty and no stamp executes.
+struct NoStamps { GL_DEV void mark(int) {} };
+struct Stamps {
+    unsigned long long last = 0, acc[20] = {};
+    GL_DEV void start() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    GL_DEV void mark(int k) {
+        unsigned long long t_;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc[k] += t_ - last; last = t_;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------- forward
 // In: v[j] = z[t + T*j].  Out: v[0..7] = Z[bA + B3*r], v[8..15] = Z[bB + B3*r] with bA = t, bB = (t ? B3 - t : B3/2).
 // `lds` is this stream's exchange area (G::LDS_SLOTS slots).  SYNC() is a barrier covering the stream's lanes.
-template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
     // ---- pass 1: NB1 radix-R1 butterflies; butterfly u holds registers j = u + NB1*m, t1 = t + T*u
     // The pass's twiddles are read into registers BEFORE any exchange store: table and exchange area live in the same
     // LDS array, so a twiddle read placed after a store could not be hoisted above it (one LDS round trip per element).
@@ -281,6 +305,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
     __builtin_amdgcn_sched_barrier(0);   // keep the twiddle reads above the butterfly: they land while it computes
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) apply_tw<false, G::NB1, G::R1>(&v[u], &w1[u]);
+    st.mark(0);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
@@ -288,6 +313,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
         for (int q = 0; q < G::R1; q++) lds[q * G::SA + t1] = v[u + G::NB1 * q];
     }
     sync();
+    st.mark(1);
     // ---- pass 2: NB2 radix-R2 butterflies beta = t + T*u2 -> (q1 = beta % R1, t2 = beta / R1)
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
@@ -296,6 +322,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
         for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * G::SA + t2 + 8 * m];
     }
     sync();
+    st.mark(2);
     V w2[16];
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
@@ -308,6 +335,7 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
+    st.mark(3);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
@@ -315,25 +343,30 @@ template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* 
         for (int q = 0; q < G::R2; q++) lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
     }
     sync();
+    st.mark(4);
     // ---- pass 3: the mirrored radix-8 butterflies bA, bB
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
 #pragma unroll
     for (int r = 0; r < 8; r++) { v[r] = lds[r * G::SB + bA]; v[8 + r] = lds[r * G::SB + bB]; }
     sync();
+    st.mark(5);
     dft8<false, 1>(&v[0]);
     dft8<false, 1>(&v[8]);
+    st.mark(6);
 }
 
 // ---------------------------------------------------------------------------------------------- inverse
 // In: v[0..7] = Z'[bA + B3*r], v[8..15] = Z'[bB + B3*r].  Out: v[j] = sum_k Z'[k] e^{+2 pi i nk/C}, n = t + T*j
 // (unnormalised; the 1/N of fft.IFFT is folded into the target magnitudes).
-template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
     dft8<true, 1>(&v[0]);
     dft8<true, 1>(&v[8]);
+    st.mark(8);
 #pragma unroll
     for (int r = 0; r < 8; r++) { lds[r * G::SB + bA] = v[r]; lds[r * G::SB + bB] = v[8 + r]; }
     sync();
+    st.mark(9);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
@@ -346,28 +379,40 @@ template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* 
         apply_tw<true, 1, G::R2>(&v[u * G::R2], w2);
     }
     sync();
+    st.mark(10);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
         dftR<true, G::R2, 1>(&v[u * G::R2]);
 #pragma unroll
-        for (int m = 0; m < G::R2; m++) lds[q1 * G::SA + t2 + 8 * m] = v[u * G::R2 + m];
+        for (int m = 0; m < G::R2; m++) lds[q1 * G::SAI + t2 + 8 * m] = v[u * G::R2 + m];
     }
     sync();
+    st.mark(11);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
         V w1[16];
 #pragma unroll
         for (int q = 0; q < G::R1; q++) {
-            v[u + G::NB1 * q] = lds[q * G::SA + t1];
+            v[u + G::NB1 * q] = lds[q * G::SAI + t1];
             if (q) w1[G::NB1 * q] = tw.tw1[q * G::C1 + t1];
         }
         apply_tw<true, G::NB1, G::R1>(&v[u], w1);
     }
     sync();
+    st.mark(12);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<true, G::R1, G::NB1>(&v[u]);
+    st.mark(13);
+}
+
+// the product form: no stamps
+template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+    NoStamps st; fft_forward<G>(v, lds, t, tw, sync, st);
+}
+template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+    NoStamps st; fft_inverse<G>(v, lds, t, tw, sync, st);
 }
 
 // ---------------------------------------------------------------------------------------------- spectral step
@@ -512,15 +557,35 @@ template <class G> __host__ __device__ inline int mag_slot_index(int k) {
     return ((e / 4) * G::T + t) * 4 + (e % 4);
 }
 
-template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restrict__ mag_row, const float* __restrict__ nyq) {
+// The loads are issued EARLY (top of the frame) and must not be waited for until the spectral step, a whole forward FFT later:
+// MagRaw holds the untouched load results; finish_mags() -- lane 0's fix-up included -- runs after fft_forward.  (Fixing lane 0 up
+// right after the loads made the wave sit out the full HBM latency of the magnitude row at the top of every frame.)
+// The Nyquist magnitude is fetched by a VECTOR load (lane t reads nyq[t & 3]; only lane 0's value is used; the array is padded
+// by 4 floats): a uniform address would become a scalar load, whose out-of-order return turns every counted LDS wait behind it
+// into lgkmcnt(0).
+struct MagRaw { v4f c0, c1, c2, c3; float nq; };
+template <class G> GL_DEV void load_mag_rows(MagRaw& r, int t, const float* __restrict__ mag_row) {
     const v4f* r4 = reinterpret_cast<const v4f*>(mag_row);
-    v4f c0 = r4[t], c1 = r4[G::T + t], c2 = r4[2 * G::T + t], c3 = r4[3 * G::T + t];
+    r.c0 = r4[t]; r.c1 = r4[G::T + t]; r.c2 = r4[2 * G::T + t]; r.c3 = r4[3 * G::T + t];
+}
+template <class G> GL_DEV void load_mags_raw(MagRaw& r, int t, const float* __restrict__ mag_row, const float* __restrict__ nyq) {
+    load_mag_rows<G>(r, t, mag_row);
+    r.nq = nyq[t & 3];
+}
+GL_DEV void finish_mags(MagRegs& m, const MagRaw& r, bool is0) {
+    const v4f c0 = r.c0, c1 = r.c1, c2 = r.c2, c3 = r.c3;
     m.ma[0] = c0.x; m.ma[1] = c0.y; m.ma[2] = c0.z; m.ma[3] = c0.w;
     m.ma[4] = c1.x; m.ma[5] = c1.y; m.ma[6] = c1.z; m.ma[7] = c1.w;
     m.mb[0] = c2.x; m.mb[1] = c2.y; m.mb[2] = c2.z; m.mb[3] = c2.w;
     m.mb[4] = c3.x; m.mb[5] = c3.y; m.mb[6] = c3.z; m.mb[7] = c3.w;
-    m.m0 = 0.f; m.mn = 0.f;
-    if (t == 0) { m.m0 = m.mb[0]; m.mb[0] = m.ma[0]; m.mn = nyq[0]; }
+    m.m0 = is0 ? m.mb[0] : 0.f;
+    m.mn = is0 ? r.nq : 0.f;
+    m.mb[0] = is0 ? m.ma[0] : m.mb[0];
+}
+template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restrict__ mag_row, const float* __restrict__ nyq) {
+    MagRaw r;
+    load_mags_raw<G>(r, t, mag_row, nyq);
+    finish_mags(m, r, t == 0);
 }
 // Wave-uniform 64-bit offset (SGPR pair): `kernel_arg_pointer + uniform offset + 32-bit lane index` lets the loads
 // use "SGPR base + VGPR offset" addressing and keeps the global address space (a pointer rebuilt from integers would

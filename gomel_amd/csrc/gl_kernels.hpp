@@ -64,7 +64,8 @@ GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
 // 256 lanes, into LDS; each row is assembled in LDS in lane-slot order (gl_fft.hpp) and leaves as one coalesced stream.
 // Channel 1 feeds bin N/2-1 only, so its exp() is taken for the one or two bands that row reads, not for all K (the fp64
 // exp() was what bounded this kernel).  Reads K*16 B, writes (N/2+1)*4 B per frame.
-constexpr int kMagFramesPerBlock = 8;
+constexpr int kMagFramesPerBlock = 8;        // fewer when NumMels is large: the exp() rows of a block must fit its LDS (launch_mel_to_mag)
+constexpr int kMaxMels = 16384;              // NumMels beyond this cannot keep one frame's exp() row in the 160 KiB LDS
 
 GL_DEV double apply_row_ch1(const BinRow r, const double* __restrict__ m) {   // apply_row on exp(channel 1), straight from the pairs
     if (r.mode == 0) return exp(m[2 * r.lo + 1]);
@@ -77,8 +78,8 @@ GL_DEV double apply_row_ch1(const BinRow r, const double* __restrict__ m) {   //
 template <int N, class MagT>
 __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
                                                     MagT* __restrict__ mag, MagT* __restrict__ nyq, int K, int64_t n_frames,
-                                                    double tune_add, double tune_mul, double inv_n) {
-    constexpr int H = N / 2, PER = H < 256 ? 1 : H / 256, FPB = kMagFramesPerBlock;   // N 256: half the block's lanes idle in the bin loops
+                                                    double tune_add, double tune_mul, double inv_n, int FPB) {
+    constexpr int H = N / 2, PER = H < 256 ? 1 : H / 256;   // N 256: half the block's lanes idle in the bin loops
     extern __shared__ double e_sh[];                       // [FPB][K] exp(channel 0), then the staged row [H] of MagT
     MagT* row = reinterpret_cast<MagT*>(e_sh + FPB * K);
     BinRow r[PER];
@@ -121,12 +122,22 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
 }
 
 template <class MagT>
-static void launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const double* mel, const BinRow* undo, MagT* mag, MagT* nyq,
-                              int K, double tune_add, double tune_mul) {
+static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const double* mel, const BinRow* undo, MagT* mag, MagT* nyq,
+                                    int K, double tune_add, double tune_mul) {
     const double inv_n = 1.0 / (double)N;
-    const unsigned blocks = (unsigned)((frames + kMagFramesPerBlock - 1) / kMagFramesPerBlock);
-    const size_t shmem = (size_t)kMagFramesPerBlock * K * 8 + (size_t)(N / 2) * sizeof(MagT);
-    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_mel_to_mag<NN, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n));
+    // frames per block: as many exp() rows as fit the default 64 KiB of dynamic LDS next to the staged output row, at most
+    // kMagFramesPerBlock; a single row that does not fit (NumMels > ~7 k) raises the kernel's limit towards the 160 KiB of the CU.
+    const size_t row_bytes = (size_t)(N / 2) * sizeof(MagT), budget = 64 * 1024;
+    int fpb = kMagFramesPerBlock;
+    while (fpb > 1 && (size_t)fpb * K * 8 + row_bytes > budget) fpb--;
+    const size_t shmem = (size_t)fpb * K * 8 + row_bytes;
+    const unsigned blocks = (unsigned)((frames + fpb - 1) / fpb);
+    hipError_t e = hipSuccess;
+    GOMEL_DISPATCH_N(N, {
+        if (shmem > budget) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_to_mag<NN, MagT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e == hipSuccess) hipLaunchKernelGGL((k_mel_to_mag<NN, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n, fpb);
+    });
+    return e;
 }
 
 // Linear magnitudes given directly (gomel_istft = the reference's exported ISTFT, mel/mel.go:76-139, which reads only
@@ -206,12 +217,17 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
     const v2f_a4* xs = reinterpret_cast<const v2f_a4*>(x + frame_xoff[frame]);
     const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
     v2f v[16], w[16], wn[8];
-    MagRegs mr;
-    load_mags<G>(mr, t, mag + frame * G::C, nyq + frame);
+    // the frame's samples first (needed at once), its magnitudes behind them (needed a forward FFT later): vmcnt is in issue order
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j];
+    MagRaw mraw;
+    load_mags_raw<G>(mraw, t, mag + frame * G::C, nyq + frame);
     load_wn<G>(wn, t, tb.wn);
 #pragma unroll
-    for (int j = 0; j < 16; j++) { w[j] = w2[t + G::T * j]; v[j] = xs[t + G::T * j] * w[j]; }
+    for (int j = 0; j < 16; j++) { w[j] = w2[t + G::T * j]; v[j] *= w[j]; }
     fft_forward<G>(v, my, t, tw, sync);
+    MagRegs mr;
+    finish_mags(mr, mraw, t == 0);
     spectral_apply<G>(v, t, mr, wn);
     fft_inverse<G>(v, my, t, tw, sync);
     if (live) {
@@ -292,6 +308,29 @@ struct SegDesc {
 };
 
 constexpr int kFusedThreads = 256;
+constexpr int kMaxSegFrames = 64;   // a wave fetches the Nyquist magnitudes of all its segment's frames with ONE load (lane = frame)
+
+// Lane-pair form of two consecutive rows.  A row is T sample pairs, one per lane (8 bytes): as such it moves with dwordx2
+// instructions, 512 B each, and what bounds the vector-memory path of a CU here is the NUMBER of wave-instructions it keeps in
+// flight, not their bytes (stamps: ~450 cycles of issue stall per load/store with 20 of them per frame).  Two rows r, r+1 are
+// therefore moved as ONE dwordx4 per lane: even lanes carry pairs (t, t+1) of row r, odd lanes pairs (t-1, t) of row r+1, and
+// one DPP exchange between quad neighbours (lane ^ 1) turns that into "row r pair t, row r+1 pair t" and back.
+GL_DEV float quad_neighbour(float x) {   // the value lane ^ 1 holds (DPP quad_perm:[1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+GL_DEV void rows_from_quad(v4f q, bool even, v2f& r0, v2f& r1) {
+    const v2f nlo = v2f{quad_neighbour(q.x), quad_neighbour(q.y)}, nhi = v2f{quad_neighbour(q.z), quad_neighbour(q.w)};
+    r0 = even ? v2f{q.x, q.y} : nhi;
+    r1 = even ? nlo : v2f{q.z, q.w};
+}
+GL_DEV v4f quad_from_rows(v2f r0, v2f r1, bool even) {
+    const v2f n0 = v2f{quad_neighbour(r0.x), quad_neighbour(r0.y)}, n1 = v2f{quad_neighbour(r1.x), quad_neighbour(r1.y)};
+    return even ? v4f{r0.x, r0.y, n0.x, n0.y} : v4f{n1.x, n1.y, r1.x, r1.y};
+}
+
+#ifdef GOMEL_STAMPS   // diagnostic build only (scripts/stamp_probe.py): per-phase cycle sums of k_gl_fused, all waves, all frames
+__device__ unsigned long long g_stamp_acc[21];
+#endif
 
 template <int N, int SH>
 __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __restrict__ x_in, const float* __restrict__ tail_in,
@@ -357,6 +396,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         g_max = d.G;
     }
 
+#ifdef GOMEL_STAMPS
+    Stamps st; st.start();
+#else
+    NoStamps st;
+#endif
     v2f xin[16], acc[KEEP];
     const v2f* wl = win_l + t;  // window pair of row j: wl[T*j]
     const v2f wt = tb.wn[t];
@@ -373,11 +417,30 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #pragma unroll
     for (int j = 0; j < KEEP; j++) acc[j] = v2f{0.f, 0.f};
 
+    // lane-pair addressing of two consecutive rows (see rows_from_quad): pair index of this lane's 16 bytes inside the row pair
+    const bool even = (t & 1) == 0;
+    const int lane_off = T * (t & 1) + (t & ~1);
+    constexpr int NPAIR = SH / 2;
+    // Nyquist magnitudes of all the segment's frames: one load per wave (lane = frame, G <= kMaxSegFrames = 64), one v_readlane
+    // per frame; narrower streams (several per wave) keep the per-frame vector load
+    float nyq_all = 0.f;
+    if constexpr (T >= 64) {
+        const int l = threadIdx.x & 63;
+        nyq_all = nyq_p[l < d.G ? l : 0];
+        // consume the load HERE: a value still "in flight" at the loop header would make the compiler put a vmcnt wait in front
+        // of the v_readlane of every frame, and vmcnt being in issue order that wait would drain the previous frame's stores
+        asm volatile("v_mov_b32 %0, %0" : "+v"(nyq_all));
+    }
+
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
-        MagRegs mr;
-        load_mags<G>(mr, t, mag_p + (int64_t)gg * G::C, nyq_p + gg);
+        // this frame's magnitudes: issued now, not touched before the spectral step (a whole forward FFT of cover)
+        MagRaw mraw;
+        load_mag_rows<G>(mraw, t, mag_p + (int64_t)gg * G::C);
+        if constexpr (T >= 64) mraw.nq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq_all), gg));
+        else mraw.nq = nyq_p[gg + (t & 3)];
+        st.mark(16);
         v2f v[16];
         // all 16 window reads go out back to back (one LDS round trip, not sixteen), then the multiplies
 #pragma unroll
@@ -385,34 +448,72 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= xin[j];
-        // slide the input window now: the next frame's SH new rows (hop samples) load behind the two FFTs
+        st.mark(17);
+        // slide the input window now: the next frame's SH new rows (hop samples) load behind the two FFTs, two rows per
+        // dwordx4; the loaded values stay RAW until the inverse FFT is done, so nothing waits for them here
 #pragma unroll
         for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];
         const bool more = g + 1 < d.G;
+        const int row0 = (g + 1) * SH + KEEP;                                // first of the SH new rows
+        v4f xq[NPAIR > 0 ? NPAIR : 1];
+        v2f xs = v2f{0.f, 0.f};
 #pragma unroll
-        for (int jj = 0; jj < SH; jj++) {
-            const int row = (g + 1) * SH + KEEP + jj;
-            const int rx = more ? row : 0;                                   // clamped: the value is unused when !more
-            const bool in_next = more && row >= rows_owned;
-            const int rn = in_next ? row - rows_owned : 0;
-            xin[KEEP + jj] = xin_p[T * rx + t] + town[T * rn + t] * (in_next ? f_next : 0.f);
+        for (int pq = 0; pq < NPAIR; pq++)
+            xq[pq] = *reinterpret_cast<const v4f*>(xin_p + T * (more ? row0 + 2 * pq : 0) + lane_off);   // clamped: unused when !more
+        if constexpr (SH & 1) xs = xin_p[T * (more ? row0 + SH - 1 : 0) + t];
+        // rows past the owned range (the last frames of a segment with a successor) also take the successor's head from the tail
+        // buffer: rare, so behind a (wave-uniform for T >= 64) branch instead of SH more loads in every frame
+        const bool any_next = more && d.has_next && row0 + SH - 1 >= rows_owned;
+        v2f tl[SH];
+        float fl[SH];
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) { tl[jj] = v2f{0.f, 0.f}; fl[jj] = 0.f; }
+        if (any_next) {
+#pragma unroll
+            for (int jj = 0; jj < SH; jj++) {
+                const bool in_next = row0 + jj >= rows_owned;
+                tl[jj] = town[T * (in_next ? row0 + jj - rows_owned : 0) + t];
+                fl[jj] = in_next ? 1.f : 0.f;
+            }
         }
-        fft_forward<G>(v, my, t, tw, sync);
+        st.mark(15);
+        fft_forward<G>(v, my, t, tw, sync, st);
         {
+            MagRegs mr;
+            finish_mags(mr, mraw, t == 0);
             v2f wn[8];
             make_wn<G>(wn, t, wt);
             spectral_apply<G>(v, t, mr, wn);
         }
-        fft_inverse<G>(v, my, t, tw, sync);
+        st.mark(7);
+        fft_inverse<G>(v, my, t, tw, sync, st);
+        // The next frame's rows: unpacked BEFORE this frame's stores are issued.  vmcnt counts loads and stores in issue order,
+        // so a wait placed behind the (conditional) stores below would have to drain them too -- a full store round trip at the
+        // end of every frame; here only loads issued a frame's worth of cycles ago are pending.
+#pragma unroll
+        for (int pq = 0; pq < NPAIR; pq++) rows_from_quad(xq[pq], even, xin[KEEP + 2 * pq], xin[KEEP + 2 * pq + 1]);
+        if constexpr (SH & 1) xin[KEEP + SH - 1] = xs;
+        if (any_next) {
+#pragma unroll
+            for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] += tl[jj] * fl[jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) asm volatile("" : "+v"(xin[KEEP + jj]));
+        __builtin_amdgcn_sched_barrier(0);
+        st.mark(18);
         if (active) {
             // overlap-add in registers: row j of this frame lands on accumulator row j (rows >= KEEP start a new sum);
-            // the first SH rows are finished by this frame and leave, the rest shift down by SH for the next frame.
+            // the first SH rows are finished by this frame and leave (two rows per dwordx4), the rest shift down by SH.
             v2f* xo = xout_p + T * (g * SH);
+            v2f yo[SH];
 #pragma unroll
             for (int j = 0; j < SH; j++) {
                 const v2f y = v[j] * wl[T * j];
-                xo[T * j + t] = (j < KEEP) ? acc[j] + y : y;
+                yo[j] = (j < KEEP) ? acc[j] + y : y;
             }
+#pragma unroll
+            for (int pq = 0; pq < NPAIR; pq++) *reinterpret_cast<v4f*>(xo + T * (2 * pq) + lane_off) = quad_from_rows(yo[2 * pq], yo[2 * pq + 1], even);
+            if constexpr (SH & 1) xo[T * (SH - 1) + t] = yo[SH - 1];
             v2f nacc[KEEP];
 #pragma unroll
             for (int j = 0; j < KEEP; j++) {
@@ -432,7 +533,14 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
                 }
             }
         }
+        st.mark(14);
     }
+#ifdef GOMEL_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 20; k++) atomicAdd(&g_stamp_acc[k], st.acc[k]);
+        atomicAdd(&g_stamp_acc[20], (unsigned long long)g_max);
+    }
+#endif
 }
 
 // out += tails (fp64), after k_finalize has converted the owned samples

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -23,6 +24,21 @@ static thread_local int g_last_hip = 0;
         hipError_t e_ = (expr);                              \
         if (e_ != hipSuccess) { g_last_hip = (int)e_; return GOMEL_ERR_HIP; } \
     } while (0)
+
+// hipSetDevice is per-thread state that outlives the call: a process driving several GPUs (torch tensors on cuda:0, a handle on
+// device 3) must find its current device unchanged after every entry point.  Entry points switch through this guard.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev != dev) { err = hipSetDevice(dev); switched = (err == hipSuccess); }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // No C++ exception crosses the C boundary: every entry point that can allocate on the host runs inside this pair.
 #define GOMEL_TRY try {
@@ -118,6 +134,19 @@ static int classify_row(double vallo, double valhi, bool undomel_rules, int limi
     return GOMEL_OK;
 }
 
+// Bounds a BinRow must meet before it is used as a device-side index: undomel rows read bands [lo, hi) or {lo, hi} of K
+// bands; domel rows read bins [lo, hi) or {lo, hi} of the N/2+1 magnitudes (channel 1 reads one bin higher).
+static bool rows_in_range(const std::vector<BinRow>& rows, int limit, bool undomel_rules) {
+    for (const BinRow& r : rows) {
+        if (r.mode < 0 || r.mode > 2 || r.lo < 0 || !std::isfinite(r.modlo) || !std::isfinite(r.div) || r.div == 0.0) return false;
+        if (r.mode == 0 && r.lo >= limit) return false;
+        if (r.mode == 1 && (r.hi < 0 || r.hi >= limit || r.lo >= limit)) return false;
+        if (r.mode == 2 && r.hi > r.lo && r.hi > limit) return false;
+        if (!undomel_rules && r.mode == 0) return false;   // domel has no copy rows
+    }
+    return true;
+}
+
 static int build_mel_tables(const gomel_config& c, std::vector<BinRow>& undo, std::vector<BinRow>& dom, int* dom_status) {
     const int H = c.resolut / 2, K = c.num_mels;
     const double fmin = c.mel_fmin, fmax = c.mel_fmax;
@@ -156,7 +185,7 @@ static void pack_tables(const gomel_config& c, int dom_status, const std::vector
 
 static int validate_config(const gomel_config* c) {
     if (!c) return GOMEL_ERR_NULL;
-    if (c->num_mels <= 0 || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
+    if (c->num_mels <= 0 || c->num_mels > kMaxMels || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
     if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
     if (!gomel_supported_n(c->resolut)) return GOMEL_ERR_UNSUPPORTED_N;
     return GOMEL_OK;
@@ -245,11 +274,16 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         h->dom.resize(K); memcpy(h->dom.data(), p, (size_t)K * sizeof(BinRow));
         h->cfg.hann_periodic = th.hann_periodic;
         h->dom_status = th.dom_status;
+        // The rows become device-side indices (k_mel_to_mag, k_domel_log): a truncated / corrupted broadcast or a blob from a
+        // build with other table logic must not reach the GPU.  Same bounds as classify_row enforces when building.
+        if (!rows_in_range(h->undo, K, true) || (th.dom_status == GOMEL_OK && !rows_in_range(h->dom, C, false))) { delete h; return GOMEL_ERR_BAD_TABLES; }
+        for (double w : h->window) if (!std::isfinite(w)) { delete h; return GOMEL_ERR_BAD_TABLES; }
     } else {
         rc = build_host_tables(*cfg, h->window, h->undo, h->dom, &h->dom_status);
         if (rc) { delete h; return rc; }
     }
-    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+    DeviceGuard dg(h->device);
+    if (dg.err != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
         if (h->stream) hipStreamDestroy(h->stream);
         delete h; return GOMEL_ERR_HIP;
@@ -262,34 +296,42 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
 
 // Pins caller-owned host buffers for the duration of a call (hipHostRegister: ~8 ms per GiB, then PCIe runs at full rate; a
 // buffer the driver has never seen copies at a tenth of that).  The runtime does not reference-count registrations, and the
-// same buffer may be passed for several utterances or by several threads / handles at once, so every range pinned by this
-// library goes through one process-wide reference-counted registry.  A refused registration (range overlapping one pinned by
-// somebody else, memory that cannot be locked, ...) simply leaves that buffer pageable.
+// same buffer (or a view into it) may be passed for several utterances or by several threads / handles at once, so every range
+// pinned by this library goes through one process-wide reference-counted INTERVAL registry: a request that lies inside a live
+// registration takes a reference on it (so the owner cannot unregister under a DMA that is still in flight).  A refused
+// registration (range pinned by somebody else, partial overlap, memory that cannot be locked, ...) leaves that buffer pageable:
+// the runtime then stages the copy itself.  gomel_host_register / gomel_host_alloc (below) let a caller that reuses its
+// buffers pay the registration once instead of per call.
 struct PinRegistry {
+    struct Entry { size_t bytes; int users; };
     std::mutex mu;
-    std::unordered_map<void*, std::pair<size_t, int>> live;   // base -> (bytes, users)
-    bool acquire(void* p, size_t bytes) {
+    std::map<uintptr_t, Entry> live;   // base -> extent, users
+    // returns the base of the registration that now covers [p, p+bytes) (a token for release), or 0
+    uintptr_t acquire(void* p, size_t bytes) {
+        const uintptr_t a = (uintptr_t)p;
         std::lock_guard<std::mutex> lk(mu);
-        auto it = live.find(p);
-        if (it != live.end()) {
-            if (it->second.first < bytes) return false;         // pinned shorter than needed: treat as not pinned
-            it->second.second++;
-            return true;
+        auto it = live.upper_bound(a);
+        if (it != live.begin()) {
+            auto pr = std::prev(it);
+            if (a + bytes <= pr->first + pr->second.bytes) { pr->second.users++; return pr->first; }   // inside a live registration
+            if (a < pr->first + pr->second.bytes) return 0;                                          // straddles its end
         }
+        if (it != live.end() && it->first < a + bytes) return 0;                                      // runs into the next one
         hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return false;  // device / already pinned
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return 0;  // device / pinned by the caller
         (void)hipGetLastError();
         const bool ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
-        if (ok) live.emplace(p, std::make_pair(bytes, 1));
-        return ok;
+        if (!ok) return 0;
+        live.emplace(a, Entry{bytes, 1});
+        return a;
     }
-    void release(void* p) {
+    void release(uintptr_t base) {
         std::lock_guard<std::mutex> lk(mu);
-        auto it = live.find(p);
+        auto it = live.find(base);
         if (it == live.end()) return;
-        if (--it->second.second == 0) {
-            (void)hipHostUnregister(p);
+        if (--it->second.users == 0) {
+            (void)hipHostUnregister((void*)base);
             (void)hipGetLastError();
             live.erase(it);
         }
@@ -297,15 +339,30 @@ struct PinRegistry {
 };
 static PinRegistry g_pins;
 
+// The buffers of ONE call.  want() only records (base, longest extent asked for) -- prefix views buf[:a], buf[:b] of one base
+// become one registration of max(a, b) bytes -- and commit() registers.  The destructor first drains the streams the call
+// copied on (every early error return still has copies queued), then drops the references.
 struct PinnedScope {
-    std::vector<void*> held;
-    void pin(const void* p, size_t bytes) {
-        if (bytes < (1u << 20)) return;
+    std::vector<std::pair<void*, size_t>> wanted;
+    std::vector<uintptr_t> held;
+    hipStream_t drain[2] = {nullptr, nullptr};
+    void want(const void* p, size_t bytes) {
+        if (!p || bytes < (1u << 20)) return;
         void* q = const_cast<void*>(p);
-        if (std::find(held.begin(), held.end(), q) != held.end()) return;   // already held by this call
-        if (g_pins.acquire(q, bytes)) held.push_back(q);
+        for (auto& w : wanted) if (w.first == q) { w.second = std::max(w.second, bytes); return; }
+        wanted.emplace_back(q, bytes);
     }
-    ~PinnedScope() { for (void* p : held) g_pins.release(p); }
+    void commit(hipStream_t s0 = nullptr, hipStream_t s1 = nullptr) {
+        drain[0] = s0; drain[1] = s1;
+        for (auto& w : wanted) if (uintptr_t t = g_pins.acquire(w.first, w.second)) held.push_back(t);
+        wanted.clear();
+    }
+    void pin(const void* p, size_t bytes, hipStream_t s0 = nullptr) { want(p, bytes); commit(s0 ? s0 : drain[0], drain[1]); }
+    ~PinnedScope() {
+        if (held.empty()) return;
+        for (hipStream_t s : drain) if (s) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); }
+        for (uintptr_t t : held) g_pins.release(t);
+    }
 };
 
 // ----------------------------------------------------------------------------------------------- batch
@@ -345,7 +402,7 @@ struct gomel_batch {
 
 static void batch_free(gomel_batch* b) {
     if (!b) return;
-    hipSetDevice(b->h->device);
+    DeviceGuard dg(b->h->device);
     void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
                     b->d_segs, b->d_tail[0], b->d_tail[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
@@ -383,13 +440,16 @@ static int64_t fused_min_frames(const gomel_config& c) {
 static void plan_segments(gomel_batch* b) {
     const gomel_config& c = b->h->cfg;
     const int sh = fused_shift(c), keep = 16 - sh, gmin = (keep + sh - 1) / sh;
-    int gt = (int)std::min<int64_t>(std::max<int64_t>(b->total_frames / 4096, gmin), 64);
-    if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) gt = std::max(v, gmin); }  // tuning knob
+    int gt = (int)std::min<int64_t>(std::max<int64_t>(b->total_frames / 4096, gmin), 48);
+    if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) gt = std::min(std::max(v, gmin), kMaxSegFrames); }  // tuning knob
     b->segs.clear();
     b->g_max = 0;
     for (const UttDesc& u : b->utts) {
         int nseg = std::max(1, (u.frames + gt / 2) / gt);
         while (nseg > 1 && u.frames / nseg < gmin) nseg--;
+        // hard cap kMaxSegFrames frames per segment (k_gl_fused keeps one Nyquist magnitude per lane); it wins over gmin, which
+        // only matters for has_next segments of very short utterances and gmin <= 15 < 64 / 2 always leaves room
+        nseg = std::max(nseg, (u.frames + kMaxSegFrames - 1) / kMaxSegFrames);
         const int base = u.frames / nseg, rem = u.frames % nseg;
         int f0 = 0;
         for (int s = 0; s < nseg; s++) {
@@ -452,7 +512,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
             if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, b->d_mel, b->d_magd, b->d_nyqd);
-            else launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul);
+            else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
             hipLaunchKernelGGL(k_init_x<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
@@ -468,7 +528,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, b->d_mel, b->d_mag, b->d_nyq);
-        else launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul);
+        else HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
         hipLaunchKernelGGL(k_init_x<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
@@ -519,7 +579,7 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     if (!h || !in || !out) return GOMEL_ERR_NULL;
     if (n_frames == 0) return GOMEL_ERR_EMPTY;
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     const int N = h->cfg.resolut;
     const size_t in_b = n_frames * (inverse ? (size_t)(N + 2) : (size_t)N) * 4, out_b = n_frames * (inverse ? (size_t)N : (size_t)(N + 2)) * 4;
     float *d_in = nullptr, *d_out = nullptr;
@@ -600,6 +660,7 @@ size_t gomel_tables_bytes(const gomel_handle* h) {
 int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap) {
     if (!h || !blob) return GOMEL_ERR_NULL;
     if (cap < gomel_tables_bytes(h)) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(const_cast<gomel_handle*>(h)->mu);   // gomel_set_window may be replacing the window
     pack_tables(h->cfg, h->dom_status, h->window, h->undo, h->dom, blob);
     return GOMEL_OK;
 }
@@ -629,7 +690,7 @@ static int set_window_guarded(gomel_handle* h, const double* w, size_t n) {
     if (!h || !w) return GOMEL_ERR_NULL;
     if (n != (size_t)h->cfg.resolut) return GOMEL_ERR_BAD_LENGTH;
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     HIPCHK(hipStreamSynchronize(h->stream));
     h->window.assign(w, w + n);
     return upload_tables(h);
@@ -638,6 +699,7 @@ static int set_window_guarded(gomel_handle* h, const double* w, size_t n) {
 int gomel_get_window(const gomel_handle* h, double* w, size_t cap) {
     if (!h || !w) return GOMEL_ERR_NULL;
     if (cap < h->window.size()) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    std::lock_guard<std::mutex> lk(const_cast<gomel_handle*>(h)->mu);
     memcpy(w, h->window.data(), h->window.size() * 8);
     return GOMEL_OK;
 }
@@ -646,6 +708,7 @@ int gomel_set_path(gomel_handle* h, int mode) {
     if (!h) return GOMEL_ERR_NULL;
     if (mode < 0 || mode > 2) return GOMEL_ERR_BAD_CONFIG;
     if (mode == 2 && !fused_applicable(h->cfg)) return GOMEL_ERR_BAD_CONFIG;
+    std::lock_guard<std::mutex> lk(h->mu);
     h->path_mode = mode;
     return GOMEL_OK;
 }
@@ -653,17 +716,20 @@ int gomel_set_path(gomel_handle* h, int mode) {
 int gomel_set_precision(gomel_handle* h, int bits) {
     if (!h) return GOMEL_ERR_NULL;
     if (bits != 32 && bits != 64) return GOMEL_ERR_BAD_CONFIG;
+    std::lock_guard<std::mutex> lk(h->mu);
     h->precision = bits;
     return GOMEL_OK;
 }
 
 int gomel_destroy(gomel_handle* h) {
     if (!h) return GOMEL_OK;
-    hipSetDevice(h->device);
+    {
+    DeviceGuard dg(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     h->pool.clear();
     if (h->d_blob) hipFree(h->d_blob);
+    }
     delete h;
     return GOMEL_OK;
 }
@@ -710,7 +776,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
     }
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     gomel_batch* b = new (std::nothrow) gomel_batch();
     if (!b) return GOMEL_ERR_NO_MEMORY;
     BatchGuard guard{b};
@@ -721,7 +787,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         d.frames = (int32_t)(n_pairs[u] / (size_t)K);
         d.len = (int64_t)N + (int64_t)(d.frames - 1) * hop;
         d.xoff = b->total_len; d.fbase = b->total_frames; d.has_x0 = 0; d.seed = u;
-        b->total_len += (d.len + 1) & ~(int64_t)1;  // keep every utterance 8-byte aligned for float2 access
+        b->total_len += (d.len + 3) & ~(int64_t)3;  // every utterance starts 16-byte aligned (float4 row pairs in k_gl_fused)
         b->total_frames += d.frames; b->total_pairs += (int64_t)n_pairs[u];
         b->max_len = std::max(b->max_len, d.len);
     }
@@ -744,7 +810,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
     } else if (I > 0) {
         alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);
-        alloc((void**)&b->d_nyq, (size_t)b->total_frames * 4);
+        alloc((void**)&b->d_nyq, ((size_t)b->total_frames + 4) * 4);   // + 4: lane t reads nyq[frame + (t & 3)] (load_mags_raw)
         alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
         alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
         if (!b->fast) alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
@@ -790,9 +856,10 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
     PinnedScope pins;
     if (pin_here)
         for (size_t u = 0; u < b->n_utt; u++) {
-            pins.pin(mel[u], b->n_pairs[u] * (b->direct ? (size_t)(h->cfg.resolut / 2 + 1) * 8 : 16));
-            if (b->utts[u].has_x0) pins.pin(x0[u], (size_t)b->utts[u].len * 8);
+            pins.want(mel[u], b->n_pairs[u] * (b->direct ? (size_t)(h->cfg.resolut / 2 + 1) * 8 : 16));
+            if (b->utts[u].has_x0) pins.want(x0[u], (size_t)b->utts[u].len * 8);
         }
+    pins.commit(h->stream);
     int64_t poff = 0;
     for (size_t u = 0; u < b->n_utt; u++) {
         const size_t row = b->direct ? (size_t)(h->cfg.resolut / 2 + 1) : 2;   // doubles per input unit (magnitude row / pair)
@@ -810,28 +877,28 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
 static int batch_upload_guarded(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
     if (!b || !mel) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
-    HIPCHK(hipSetDevice(b->h->device));
+    DeviceGuard dg(b->h->device); HIPCHK(dg.err);
     return batch_upload_impl(b, mel, x0, seeds, true, true);
 }
 
 static int batch_run_guarded(gomel_batch* b) {
     if (!b) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
-    HIPCHK(hipSetDevice(b->h->device));
+    DeviceGuard dg(b->h->device); HIPCHK(dg.err);
     return batch_run_impl(b, nullptr);
 }
 
 static int batch_run_timed_guarded(gomel_batch* b, gomel_timing* t) {
     if (!b || !t) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
-    HIPCHK(hipSetDevice(b->h->device));
+    DeviceGuard dg(b->h->device); HIPCHK(dg.err);
     return batch_run_impl(b, t);
 }
 
 int gomel_batch_sync(gomel_batch* b) {
     if (!b) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(b->h->mu);
-    HIPCHK(hipSetDevice(b->h->device));
+    DeviceGuard dg(b->h->device); HIPCHK(dg.err);
     HIPCHK(hipStreamSynchronize(b->h->stream));
     return GOMEL_OK;
 }
@@ -840,13 +907,14 @@ static int batch_download_guarded(gomel_batch* b, double* const* out, const size
     if (!b || !out) return GOMEL_ERR_NULL;
     gomel_handle* h = b->h;
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     for (size_t u = 0; u < b->n_utt; u++) {
         if (!out[u]) return GOMEL_ERR_NULL;
         if (out_cap && out_cap[u] < (size_t)b->utts[u].len) return GOMEL_ERR_BUFFER_TOO_SMALL;
     }
     PinnedScope pins;
-    for (size_t u = 0; u < b->n_utt; u++) pins.pin(out[u], (size_t)b->utts[u].len * 8);
+    for (size_t u = 0; u < b->n_utt; u++) pins.want(out[u], (size_t)b->utts[u].len * 8);
+    pins.commit(h->stream);
     for (size_t u = 0; u < b->n_utt; u++)
         HIPCHK(hipMemcpyAsync(out[u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -856,7 +924,7 @@ static int batch_download_guarded(gomel_batch* b, double* const* out, const size
 int gomel_batch_destroy(gomel_batch* b) {
     if (!b) return GOMEL_OK;
     std::lock_guard<std::mutex> lk(b->h->mu);
-    hipSetDevice(b->h->device);
+    DeviceGuard dg(b->h->device);
     hipStreamSynchronize(b->h->stream);
     batch_free(b);
     return GOMEL_OK;
@@ -905,14 +973,16 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* c
     for (int c = 0; c < n_chunks && !rc; c++) rc = gomel_batch_create(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], &chunks[c]);
     if (!rc) {
         std::lock_guard<std::mutex> lk(h->mu);
-        if (hipSetDevice(h->device) != hipSuccess) rc = GOMEL_ERR_HIP;
+        DeviceGuard dg(h->device);
+        if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
         PinnedScope pins;
         std::vector<hipEvent_t> done((size_t)n_chunks, nullptr);
         for (size_t u = 0; u < n_utt && !rc; u++) {
-            pins.pin(mel[u], n_pairs[u] * 16);
-            pins.pin(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
-            if (x0 && x0[u]) pins.pin(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
+            pins.want(mel[u], n_pairs[u] * 16);
+            pins.want(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
+            if (x0 && x0[u]) pins.want(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
         }
+        pins.commit(h->stream, h->copy_stream);
         for (int c = 0; c < n_chunks && !rc; c++) {
             gomel_batch* b = chunks[c];
             const size_t u0 = bounds[c];
@@ -961,7 +1031,8 @@ static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, i
     if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(h->mu);
-        if (hipSetDevice(h->device) != hipSuccess) rc = GOMEL_ERR_HIP;
+        DeviceGuard dg(h->device);
+        if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
         const double* ins[1] = {mags};
         const double* x0s[1] = {x0};
         if (!rc) rc = batch_upload_impl(b, ins, x0s, &seed, true, true);
@@ -984,14 +1055,14 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
     if (n_pairs % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
     const size_t F = n_pairs / (size_t)K;  // (rows come back in lane-slot order and are un-permuted below)
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     double* d_mel = nullptr; float *d_mag = nullptr, *d_nyq = nullptr;
     int rc = GOMEL_OK;
     if (h->pool.alloc((void**)&d_mel, n_pairs * 16) != hipSuccess || h->pool.alloc((void**)&d_mag, F * H * 4) != hipSuccess ||
         h->pool.alloc((void**)&d_nyq, F * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc && hipMemcpyAsync(d_mel, mel, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
-        launch_mel_to_mag<float>(N, (int64_t)F, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul);
+        if (launch_mel_to_mag<float>(N, (int64_t)F, h->stream, d_mel, h->dt.undo, d_mag, d_nyq, K, h->cfg.tune_add, h->cfg.tune_mul) != hipSuccess) rc = GOMEL_ERR_HIP;
         std::vector<float> mg(F * H), ny(F);
         if (hipMemcpyAsync(mg.data(), d_mag, F * H * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipMemcpyAsync(ny.data(), d_nyq, F * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
@@ -1031,12 +1102,13 @@ static int to_mel_guarded(gomel_handle* h, const double* wave, size_t n, double*
     const size_t pairs = gomel_to_mel_pairs(&c, n), F = pairs / (size_t)K;    // gossp NumFrames
     if (cap_pairs < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;                      // big caller buffers: pinned for the call (pageable copies run at a tenth of the rate)
-    pins.pin(wave, n * 8);
-    pins.pin(out_pairs, pairs * 16);
+    pins.want(wave, n * 8);
+    pins.want(out_pairs, pairs * 16);
+    pins.commit(h->stream);
     if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, F * (size_t)(H + 1) * 8) != hipSuccess ||
         h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
@@ -1082,12 +1154,13 @@ static int to_phase_guarded(gomel_handle* h, int32_t num_freqs, const double* wa
     const size_t pairs = gomel_phase_pairs(&c, num_freqs, n), F = pairs / (size_t)nf;
     if (cap_pairs < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     double *d_wave = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;
-    pins.pin(wave, n * 8);
-    pins.pin(out_pairs, pairs * 16);
+    pins.want(wave, n * 8);
+    pins.want(out_pairs, pairs * 16);
+    pins.commit(h->stream);
     if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
                 hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
@@ -1122,12 +1195,13 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
         for (double v : ws) mx = std::max(mx, v);
     }
     std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device); HIPCHK(dg.err);
     double *d_in = nullptr, *d_yw = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;
-    pins.pin(pairs, n_pairs * 16);
-    pins.pin(out, L * 8);
+    pins.want(pairs, n_pairs * 16);
+    pins.want(out, L * 8);
+    pins.commit(h->stream);
     if (h->pool.alloc((void**)&d_in, n_pairs * 16) != hipSuccess || h->pool.alloc((void**)&d_yw, F * (size_t)N * 8) != hipSuccess ||
         h->pool.alloc((void**)&d_out, L * 8) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     if (!rc && hipMemcpyAsync(d_in, pairs, n_pairs * 16, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
@@ -1146,6 +1220,14 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
     if (!rc && out_len) *out_len = L;
     return rc;
 }
+
+#ifdef GOMEL_STAMPS   // diagnostic build only: read (and clear) the per-phase cycle sums of k_gl_fused
+int gomel_debug_stamps(unsigned long long* out21, int clear) {
+    if (out21 && hipMemcpyFromSymbol(out21, HIP_SYMBOL(g_stamp_acc), 21 * sizeof(unsigned long long)) != hipSuccess) return GOMEL_ERR_HIP;
+    if (clear) { unsigned long long z[21] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof z) != hipSuccess) return GOMEL_ERR_HIP; }
+    return GOMEL_OK;
+}
+#endif
 
 // ---- exception firewall: the entry points that allocate on the host
 int gomel_set_window(gomel_handle* h, const double* w, size_t n) {

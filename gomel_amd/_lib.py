@@ -46,6 +46,20 @@ SYMBOLS = {
                                       ctypes.c_size_t, c_size_p]),
     "gomel_istft": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, ctypes.c_int32, c_double_p, ctypes.c_uint64, c_double_p,
                                    ctypes.c_size_t, c_size_p]),
+    "gomel_istft_spec": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, ctypes.c_int32, c_double_p, ctypes.c_uint64, c_double_p,
+                                        ctypes.c_size_t, c_size_p, c_double_p]),
+    "gomel_from_mel_batch_f32": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_float_p), c_size_p,
+                                                ctypes.POINTER(c_float_p), c_u64_p, ctypes.POINTER(c_float_p), c_size_p]),
+    "gomel_from_mel_batch_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p,
+                                                  ctypes.POINTER(c_double_p), c_u64_p, ctypes.POINTER(c_double_p), c_size_p]),
+    "gomel_host_alloc": (_vp, [ctypes.c_size_t]),
+    "gomel_host_free": (ctypes.c_int, [_vp]),
+    "gomel_host_register": (ctypes.c_int, [_vp, ctypes.c_size_t]),
+    "gomel_host_unregister": (ctypes.c_int, [_vp]),
+    "gomel_batch_create_f32": (ctypes.c_int, [_vp, ctypes.c_size_t, c_size_p, ctypes.POINTER(_vp)]),
+    "gomel_batch_upload_f32": (ctypes.c_int, [_vp, ctypes.POINTER(c_float_p), ctypes.POINTER(c_float_p), c_u64_p]),
+    "gomel_batch_download_f32": (ctypes.c_int, [_vp, ctypes.POINTER(c_float_p), c_size_p]),
+    "gomel_to_mel_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p, ctypes.POINTER(c_double_p), c_size_p, c_size_p]),
     "gomel_from_mel_batch": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p,
                                             ctypes.POINTER(c_double_p), c_u64_p, ctypes.POINTER(c_double_p), c_size_p]),
     "gomel_batch_create": (ctypes.c_int, [_vp, ctypes.c_size_t, c_size_p, ctypes.POINTER(_vp)]),

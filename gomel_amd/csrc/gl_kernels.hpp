@@ -67,16 +67,18 @@ GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
 constexpr int kMagFramesPerBlock = 8;        // fewer when NumMels is large: the exp() rows of a block must fit its LDS (launch_mel_to_mag)
 constexpr int kMaxMels = 16384;              // NumMels beyond this cannot keep one frame's exp() row in the 160 KiB LDS
 
-GL_DEV double apply_row_ch1(const BinRow r, const double* __restrict__ m) {   // apply_row on exp(channel 1), straight from the pairs
-    if (r.mode == 0) return exp(m[2 * r.lo + 1]);
-    if (r.mode == 1) return exp(m[2 * r.lo + 1]) * (1 - r.modlo) + exp(m[2 * r.hi + 1]) * r.modlo;
+template <class InT> GL_DEV double apply_row_ch1(const BinRow r, const InT* __restrict__ m) {   // apply_row on exp(channel 1), straight from the pairs
+    if (r.mode == 0) return exp((double)m[2 * r.lo + 1]);
+    if (r.mode == 1) return exp((double)m[2 * r.lo + 1]) * (1 - r.modlo) + exp((double)m[2 * r.hi + 1]) * r.modlo;
     double tot = 0;
-    for (int k = r.lo; k < r.hi; k++) tot += exp(m[2 * k + 1]);
+    for (int k = r.lo; k < r.hi; k++) tot += exp((double)m[2 * k + 1]);
     return tot / r.div;
 }
 
-template <int N, class MagT>
-__global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ mel, const BinRow* __restrict__ undo,
+// InT: element type of the log-mel pairs as the caller handed them over (double: the Go API's [][2]float64; float: the fp32
+// host-I/O entry points).  The arithmetic is fp64 either way.
+template <int N, class MagT, class InT>
+__global__ __launch_bounds__(256) void k_mel_to_mag(const InT* __restrict__ mel, const BinRow* __restrict__ undo,
                                                     MagT* __restrict__ mag, MagT* __restrict__ nyq, int K, int64_t n_frames,
                                                     double tune_add, double tune_mul, double inv_n, int FPB) {
     constexpr int H = N / 2, PER = H < 256 ? 1 : H / 256;   // N 256: half the block's lanes idle in the bin loops
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
     const bool unit_mul = tune_mul == 1.0;                 // kernel-argument uniform
     const int64_t f0 = (int64_t)blockIdx.x * FPB;
     const int nf = (int)(n_frames - f0 < FPB ? n_frames - f0 : FPB);
-    const double* m0 = mel + f0 * (int64_t)K * 2;
-    for (int k = threadIdx.x; k < nf * K; k += 256) e_sh[k] = exp(m0[2 * k]);   // frame-major: e_sh[ff*K + band]
+    const InT* m0 = mel + f0 * (int64_t)K * 2;
+    for (int k = threadIdx.x; k < nf * K; k += 256) e_sh[k] = exp((double)m0[2 * k]);   // frame-major: e_sh[ff*K + band]
     __syncthreads();
     for (int ff = 0; ff < nf; ff++) {
         const int64_t f = f0 + ff;
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const double* __restrict__ m
     }
 }
 
-template <class MagT>
-static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const double* mel, const BinRow* undo, MagT* mag, MagT* nyq,
+template <class MagT, class InT>
+static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const InT* mel, const BinRow* undo, MagT* mag, MagT* nyq,
                                     int K, double tune_add, double tune_mul) {
     const double inv_n = 1.0 / (double)N;
     // frames per block: as many exp() rows as fit the default 64 KiB of dynamic LDS next to the staged output row, at most
@@ -134,8 +136,8 @@ static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const 
     const unsigned blocks = (unsigned)((frames + fpb - 1) / fpb);
     hipError_t e = hipSuccess;
     GOMEL_DISPATCH_N(N, {
-        if (shmem > budget) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_to_mag<NN, MagT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e == hipSuccess) hipLaunchKernelGGL((k_mel_to_mag<NN, MagT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n, fpb);
+        if (shmem > budget) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_to_mag<NN, MagT, InT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e == hipSuccess) hipLaunchKernelGGL((k_mel_to_mag<NN, MagT, InT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n, fpb);
     });
     return e;
 }
@@ -176,19 +178,20 @@ struct UttDesc {  // one utterance of a batch
     uint64_t seed;
 };
 
-template <class OutT>
-__global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, int n_utt, const double* __restrict__ x0, OutT* __restrict__ x) {
+template <class OutT, class InT>
+__global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, int n_utt, const InT* __restrict__ x0, OutT* __restrict__ x) {
     for (int iu = blockIdx.y; iu < n_utt; iu += gridDim.y) {   // grid.y is capped at 65535: batches of more utterances stride
         const UttDesc u = utts[iu];
         for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
-            double v = u.has_x0 ? x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
+            double v = u.has_x0 ? (double)x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
             x[u.xoff + n] = (OutT)v;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, double* __restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (double)x[i];
+template <class OutT>
+__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, OutT* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (OutT)x[i];
 }
 
 // =============================================================================================== generic path: frames kernel
@@ -544,13 +547,16 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 }
 
 // out += tails (fp64), after k_finalize has converted the owned samples
-__global__ __launch_bounds__(256) void k_add_tails(const SegDesc* __restrict__ segs, const float* __restrict__ tail, double* __restrict__ out,
+// (x and the tail are both fp32: the sum is formed in fp32 first when the output is fp32, exactly as the next iteration would
+// have read it, and in fp64 when the output is fp64)
+template <class OutT>
+__global__ __launch_bounds__(256) void k_add_tails(const SegDesc* __restrict__ segs, const float* __restrict__ tail, OutT* __restrict__ out,
                                                    int tail_len, int hop) {
     const SegDesc d = segs[blockIdx.x];
     if (!d.has_next) return;
-    double* o = out + d.s0 + (int64_t)d.G * hop;
+    OutT* o = out + d.s0 + (int64_t)d.G * hop;
     const float* tp = tail + (int64_t)blockIdx.x * tail_len;
-    for (int i = threadIdx.x; i < tail_len; i += blockDim.x) o[i] += (double)tp[i];
+    for (int i = threadIdx.x; i < tail_len; i += blockDim.x) o[i] += (OutT)tp[i];
 }
 
 
@@ -559,7 +565,8 @@ __global__ __launch_bounds__(256) void k_add_tails(const SegDesc* __restrict__ s
 // |S[N-1-j]| = |S[j+1]|, so one array of N/2+1 magnitudes serves both channels).  fp64 because ln() of bins near the
 // 1e-5 floor needs more dynamic range than an fp32 FFT keeps.
 template <int N>
-__global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wave, double* __restrict__ smag, int64_t n_frames, int hop, DevTables tb) {
+__global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wave, const int64_t* __restrict__ frame_off, double* __restrict__ smag,
+                                                  int64_t n_frames, int hop, DevTables tb) {
     typedef Geo<N> G;
     constexpr int STREAMS = 128 / G::T;
     __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wav
     v2d* my = lds + stream * G::LDS_SLOTS;
     const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
     auto sync = [] { __syncthreads(); };
-    const double* xs = wave + frame * hop;
+    const double* xs = wave + (frame_off ? frame_off[frame] : frame * hop);   // batched ToMel: frames of many utterances, offsets from the host
     v2d v[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -722,6 +729,74 @@ __global__ __launch_bounds__(256) void k_phase_ola(const double* __restrict__ yw
         else if (ws > 1e-21) acc = acc / ws * (ws / thr);
         if (boost != 0.0) acc *= boost;
         out[n] = acc;
+    }
+}
+
+// =============================================================================================== ISTFT's side effect on its argument
+// mel/mel.go:98-108: every iteration overwrites the caller's spectrogram[i][j] with Rect(Abs(spectrogram[i][j]), Phase(S[j])) and
+// conjugate-fills the upper half, so after the call it holds the LAST iteration's phase estimate (of the signal BEFORE the last
+// update) on the caller's magnitudes.  This kernel recomputes that from x_{I-1}: frame * Hann -> real FFT -> unit phasor (the
+// reference's Phase(0) = 0 rule) times |magnitude| as the caller gave it (fp64), bins 0 ... N/2; the shim mirrors the rest.
+template <class V> struct TabOf;
+template <> struct TabOf<v2f> {
+    typedef float S;
+    static GL_DEV Twiddles<v2f> tw(const DevTables& tb) { return Twiddles<v2f>{tb.tw1, tb.tw2, tb.wn}; }
+    static GL_DEV const v2f* win(const DevTables& tb) { return reinterpret_cast<const v2f*>(tb.window); }
+};
+template <> struct TabOf<v2d> {
+    typedef double S;
+    static GL_DEV Twiddles<v2d> tw(const DevTables& tb) { return Twiddles<v2d>{tb.tw1d, tb.tw2d, tb.wnd}; }
+    static GL_DEV const v2d* win(const DevTables& tb) { return reinterpret_cast<const v2d*>(tb.windowd); }
+};
+
+template <int N, class V>
+__global__ __launch_bounds__(128) void k_spec_writeback(const typename TabOf<V>::S* __restrict__ x, const int64_t* __restrict__ frame_xoff,
+                                                        const double* __restrict__ mags, double* __restrict__ spec, int64_t n_frames, DevTables tb) {
+    typedef Geo<N> G;
+    typedef typename TabOf<V>::S S;
+    constexpr int STREAMS = 128 / G::T;
+    __shared__ V lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / G::T, t = threadIdx.x % G::T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    V* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<V> tw = TabOf<V>::tw(tb);
+    auto sync = [] { __syncthreads(); };
+    typedef V Va __attribute__((aligned(sizeof(S))));
+    const Va* xs = reinterpret_cast<const Va*>(x + frame_xoff[frame]);
+    const V* w2 = TabOf<V>::win(tb);
+    V v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j] * w2[t + G::T * j];
+    fft_forward<G>(v, my, t, tw, sync);
+    if (!live) return;
+    const double* m = mags + frame * (G::C + 1);
+    v2d* out = reinterpret_cast<v2d*>(spec) + frame * (G::C + 1);
+    auto put = [&](int k, double re, double im) {       // Rect(|m[k]|, atan2(im, re)) with Phase(0) = 0
+        const double a = fabs(m[k]), big = fmax(fabs(re), fabs(im));
+        if (!(big > 0.0)) { out[k] = v2d{a, 0.0}; return; }
+        const double sc = 1.0 / big, yr = re * sc, yi = im * sc, r = 1.0 / sqrt(yr * yr + yi * yi);
+        out[k] = v2d{a * (yr * r), a * (yi * r)};
+    };
+    const bool is0 = (t == 0);
+    const V dc = v[0];
+    lane0_permute<G>(v, is0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int k = slot_bin<G>(t, s);
+        const V a = v[s], b = v[15 - s], wk = tw.wn[k];
+        const V bc = V{b.x, -b.y};
+        const V p = a + bc, d = a - bc;
+        const V q = cmul(wk, V{d.y, -d.x});
+        const V xk = p + q, xc = p - q;                // 2 X[k], 2 conj(X[C-k])
+        put(k, (double)xk.x, (double)xk.y);
+        put(G::C - k, (double)xc.x, -(double)xc.y);
+    }
+    if (is0) {   // bins 0 and N/2 are real: phase 0 or pi; Go's Rect(m, pi) = (-m, m sin(pi)) with sin(pi) = 1.2246e-16 in fp64
+        const double x0 = (double)dc.x + (double)dc.y, xn = (double)dc.x - (double)dc.y, a0 = fabs(m[0]), an = fabs(m[G::C]);
+        out[0] = x0 < 0.0 ? v2d{-a0, a0 * 1.2246467991473532e-16} : v2d{a0, 0.0};
+        out[G::C] = xn < 0.0 ? v2d{-an, an * 1.2246467991473532e-16} : v2d{an, 0.0};
     }
 }
 

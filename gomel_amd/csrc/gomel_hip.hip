@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -102,6 +103,7 @@ struct gomel_handle {
     int device = 0;
     hipStream_t stream = nullptr;       // compute (and H2D)
     hipStream_t copy_stream = nullptr;  // D2H of finished chunks, overlapped with the next chunk's compute
+    hipStream_t up_stream = nullptr;    // H2D of the next chunk, overlapped with this chunk's compute
     std::mutex mu;
     int path_mode = 0;
     int precision = 32;           // 32: fp32 kernels (default); 64: fp64 generic kernels ("precise" mode)
@@ -284,12 +286,14 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     }
     DeviceGuard dg(h->device);
     if (dg.err != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking) != hipSuccess) {
         if (h->stream) hipStreamDestroy(h->stream);
+        if (h->copy_stream) hipStreamDestroy(h->copy_stream);
         delete h; return GOMEL_ERR_HIP;
     }
     rc = upload_tables(h);
-    if (rc) { hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
+    if (rc) { hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); hipStreamDestroy(h->up_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
     *out = h;
     return GOMEL_OK;
 }
@@ -376,10 +380,14 @@ struct gomel_batch {
     int fast = 0;
     int direct = 0;            // gomel_istft: d_mel holds linear magnitudes [total_frames][N/2+1] instead of log-mel pairs
     int iters = -1;            // >= 0: overrides cfg.griffin_lim_iterations (ISTFT's numIterations argument)
+    int io32 = 0;              // the caller's buffers (log-mel, x0, waveforms) are float instead of double (gomel_from_mel_batch_f32)
+    size_t esz = 8;            // bytes per element of d_mel / d_x0 / d_out
+    int want_spec = 0;         // gomel_istft_spec: keep x_{I-1} reachable (generic kernels) and fill d_spec after the last iteration
     // device
-    double* d_mel = nullptr;   // [total_pairs][2]
-    double* d_x0 = nullptr;    // [total_len] (only when some x0 is given)
-    double* d_out = nullptr;   // [total_len]
+    void* d_mel = nullptr;     // [total_pairs][2] (or, direct: [total_frames][N/2+1]) of esz-byte elements
+    void* d_x0 = nullptr;      // [total_len] (only when some x0 is given)
+    void* d_out = nullptr;     // [total_len]
+    double* d_spec = nullptr;  // [total_frames][N/2+1][2]: ISTFT's side effect on its spectrogram argument (mel/mel.go:98-108)
     float* d_mag = nullptr;    // [total_frames][N/2]
     float* d_nyq = nullptr;    // [total_frames]
     float* d_x[2] = {nullptr, nullptr};  // ping-pong signal
@@ -403,7 +411,7 @@ struct gomel_batch {
 static void batch_free(gomel_batch* b) {
     if (!b) return;
     DeviceGuard dg(b->h->device);
-    void* ptrs[] = {b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
+    void* ptrs[] = {b->d_spec, b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
                     b->d_segs, b->d_tail[0], b->d_tail[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
@@ -505,15 +513,19 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         HIPCHK(hipEventRecord(b->ev[0], s));
     }
     const unsigned gx = (unsigned)std::min<int64_t>((b->max_len + 255) / 256, 4096), gy = (unsigned)std::min<size_t>(b->n_utt, 65535);
+    const double* mel64 = (const double*)b->d_mel; const float* mel32 = (const float*)b->d_mel;
+    const double* x064 = (const double*)b->d_x0;   const float* x032 = (const float*)b->d_x0;
+    double* out64 = (double*)b->d_out;             float* out32 = (float*)b->d_out;
     if (I == 0) {
-        // "I = 0 returns the random init" (mel/mel.go:85 never runs): keep it in fp64
-        hipLaunchKernelGGL(k_init_x<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_out);
+        // "I = 0 returns the random init" (mel/mel.go:85 never runs): keep it in the caller's precision
+        if (b->io32) hipLaunchKernelGGL((k_init_x<float, float>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x032, out32);
+        else hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, out64);
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
-            if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, b->d_mel, b->d_magd, b->d_nyqd);
-            else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
-            hipLaunchKernelGGL(k_init_x<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_xd[0]);
+            if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
+            else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
+            hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
             const int64_t spb = 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
@@ -525,11 +537,15 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 curd ^= 1;
             }
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
+            if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
+                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
             HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
         } else {
-        if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, b->d_mel, b->d_mag, b->d_nyq);
-        else HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, b->d_mel, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
-        hipLaunchKernelGGL(k_init_x<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_x0, b->d_x[0]);
+        if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
+        else if (b->io32) HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel32, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
+        else HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel64, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
+        if (b->io32) hipLaunchKernelGGL((k_init_x<float, float>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x032, b->d_x[0]);
+        else hipLaunchKernelGGL((k_init_x<float, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_x[0]);
         if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
         int cur = 0;
         const size_t tail_bytes = b->segs.size() * (size_t)(N - c.window) * 4;
@@ -543,9 +559,19 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             cur ^= 1;
         }
         if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
+        if (b->want_spec) {   // generic kernels were forced: d_x[cur ^ 1] is x_{I-1}, contiguous
+            constexpr int dummy = 0; (void)dummy;
+            GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;
+                                  hipLaunchKernelGGL((k_spec_writeback<NN, v2f>), dim3((unsigned)((b->total_frames + SPB - 1) / SPB)), dim3(128), 0, s, b->d_x[cur ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt); });
+        }
         const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
-        hipLaunchKernelGGL(k_finalize, dim3(gf), dim3(256), 0, s, b->d_x[cur], b->d_out, b->total_len);
-        if (b->fast) hipLaunchKernelGGL(k_add_tails, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], b->d_out, N - c.window, c.window);
+        if (b->io32) {
+            hipLaunchKernelGGL(k_finalize<float>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out32, b->total_len);
+            if (b->fast) hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out32, N - c.window, c.window);
+        } else {
+            hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
+            if (b->fast) hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
+        }
         }
     }
     HIPCHK(hipGetLastError());
@@ -727,6 +753,7 @@ int gomel_destroy(gomel_handle* h) {
     DeviceGuard dg(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    if (h->up_stream) { hipStreamSynchronize(h->up_stream); hipStreamDestroy(h->up_stream); }
     h->pool.clear();
     if (h->d_blob) hipFree(h->d_blob);
     }
@@ -765,7 +792,9 @@ int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.g
 
 // One plan for both kinds of input: log-mel pairs (n_pairs[u] = frames * NumMels) or, for gomel_istft, linear magnitudes
 // (`direct`: n_pairs[u] = frames, rows of N/2+1 doubles).  `iters` >= 0 overrides the configured iteration count.
-static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pairs, int direct, int iters, gomel_batch** out) {
+enum { BF_DIRECT = 1, BF_IO32 = 2, BF_SPEC = 4 };   // batch_create_common flags
+static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pairs, int flags, int iters, gomel_batch** out) {
+    const int direct = (flags & BF_DIRECT) ? 1 : 0;
     if (!h || !n_pairs || !out) return GOMEL_ERR_NULL;
     *out = nullptr;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
@@ -781,6 +810,8 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     if (!b) return GOMEL_ERR_NO_MEMORY;
     BatchGuard guard{b};
     b->h = h; b->n_utt = n_utt; b->direct = direct; b->iters = iters;
+    b->io32 = (flags & BF_IO32) ? 1 : 0; b->esz = b->io32 ? 4 : 8; b->want_spec = (flags & BF_SPEC) ? 1 : 0;
+    if (b->io32 && (direct || h->precision == 64)) return GOMEL_ERR_BAD_CONFIG;   // fp32 host I/O: log-mel entry points, fp32 kernels
     b->utts.resize(n_utt); b->n_pairs.assign(n_pairs, n_pairs + n_utt);
     for (size_t u = 0; u < n_utt; u++) {
         UttDesc& d = b->utts[u];
@@ -794,12 +825,13 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // Path choice: the fused kernel walks consecutive frames per stream, which only pays once there are enough frames to fill
     // the chip (fused_min_frames); below that every frame in parallel (generic kernels) is faster.
     b->precise = h->precision == 64 ? 1 : 0;
-    b->fast = (!b->precise && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;
+    b->fast = (!b->precise && !b->want_spec && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
-    alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * (size_t)(N / 2 + 1) * 8 : (size_t)b->total_pairs * 16);
-    alloc((void**)&b->d_out, (size_t)b->total_len * 8);
+    alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * (size_t)(N / 2 + 1) * 8 : (size_t)b->total_pairs * 2 * b->esz);
+    alloc((void**)&b->d_out, (size_t)b->total_len * b->esz);
+    if (b->want_spec && I > 0) alloc((void**)&b->d_spec, (size_t)b->total_frames * (size_t)(N / 2 + 1) * 16);
     alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
     if (I > 0 && b->precise) {
         alloc((void**)&b->d_magd, (size_t)b->total_frames * (N / 2) * 8);
@@ -841,10 +873,15 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
 static int batch_create_guarded(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
     return batch_create_common(h, n_utt, n_pairs, 0, -1, out);
 }
+static int batch_create_f32_guarded(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+    return batch_create_common(h, n_utt, n_pairs, BF_IO32, -1, out);
+}
 
-// H2D of log-mel and x0 on the compute stream (asynchronous when `pins` already covers the host buffers).
-static int batch_upload_impl(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds, bool pin_here, bool wait) {
+// H2D of log-mel and x0 on `st` (asynchronous when the host buffers are pinned).  Pointers are to esz-byte elements.
+static int batch_upload_impl(gomel_batch* b, const void* const* mel, const void* const* x0, const uint64_t* seeds, bool pin_here, bool wait,
+                             hipStream_t st) {
     gomel_handle* h = b->h;
+    const size_t esz = b->esz;
     b->any_x0 = false;
     for (size_t u = 0; u < b->n_utt; u++) {
         if (!mel[u]) return GOMEL_ERR_NULL;
@@ -852,33 +889,34 @@ static int batch_upload_impl(gomel_batch* b, const double* const* mel, const dou
         b->utts[u].seed = seeds ? seeds[u] : (uint64_t)u;
         b->any_x0 |= b->utts[u].has_x0 != 0;
     }
-    if (b->any_x0 && !b->d_x0) HIPCHK(h->pool.alloc((void**)&b->d_x0, (size_t)b->total_len * 8));
+    if (b->any_x0 && !b->d_x0) HIPCHK(h->pool.alloc((void**)&b->d_x0, (size_t)b->total_len * esz));
     PinnedScope pins;
+    const size_t row = b->direct ? (size_t)(h->cfg.resolut / 2 + 1) : 2;   // elements per input unit (magnitude row / pair)
     if (pin_here)
         for (size_t u = 0; u < b->n_utt; u++) {
-            pins.want(mel[u], b->n_pairs[u] * (b->direct ? (size_t)(h->cfg.resolut / 2 + 1) * 8 : 16));
-            if (b->utts[u].has_x0) pins.want(x0[u], (size_t)b->utts[u].len * 8);
+            pins.want(mel[u], b->n_pairs[u] * row * esz);
+            if (b->utts[u].has_x0) pins.want(x0[u], (size_t)b->utts[u].len * esz);
         }
-    pins.commit(h->stream);
+    pins.commit(st);
     int64_t poff = 0;
     for (size_t u = 0; u < b->n_utt; u++) {
-        const size_t row = b->direct ? (size_t)(h->cfg.resolut / 2 + 1) : 2;   // doubles per input unit (magnitude row / pair)
-        HIPCHK(hipMemcpyAsync(b->d_mel + poff * (int64_t)row, mel[u], b->n_pairs[u] * row * 8, hipMemcpyDefault, h->stream));
+        HIPCHK(hipMemcpyAsync((char*)b->d_mel + (size_t)poff * row * esz, mel[u], b->n_pairs[u] * row * esz, hipMemcpyDefault, st));
         poff += (int64_t)b->n_pairs[u];
         if (b->utts[u].has_x0)
-            HIPCHK(hipMemcpyAsync(b->d_x0 + b->utts[u].xoff, x0[u], (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->stream));
+            HIPCHK(hipMemcpyAsync((char*)b->d_x0 + (size_t)b->utts[u].xoff * esz, x0[u], (size_t)b->utts[u].len * esz, hipMemcpyDefault, st));
     }
-    HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, h->stream));
-    if (wait || pin_here) HIPCHK(hipStreamSynchronize(h->stream));   // the local pins must outlive the copies
+    HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, st));
+    if (wait || pin_here) HIPCHK(hipStreamSynchronize(st));   // the local pins must outlive the copies
     b->uploaded = true;
     return GOMEL_OK;
 }
 
-static int batch_upload_guarded(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
+static int batch_upload_guarded(gomel_batch* b, const void* const* mel, const void* const* x0, const uint64_t* seeds, int io32) {
     if (!b || !mel) return GOMEL_ERR_NULL;
+    if (b->io32 != io32) return GOMEL_ERR_BAD_CONFIG;   // a batch created for one element type was handed the other
     std::lock_guard<std::mutex> lk(b->h->mu);
     DeviceGuard dg(b->h->device); HIPCHK(dg.err);
-    return batch_upload_impl(b, mel, x0, seeds, true, true);
+    return batch_upload_impl(b, mel, x0, seeds, true, true, b->h->stream);
 }
 
 static int batch_run_guarded(gomel_batch* b) {
@@ -903,8 +941,9 @@ int gomel_batch_sync(gomel_batch* b) {
     return GOMEL_OK;
 }
 
-static int batch_download_guarded(gomel_batch* b, double* const* out, const size_t* out_cap) {
+static int batch_download_guarded(gomel_batch* b, void* const* out, const size_t* out_cap, int io32) {
     if (!b || !out) return GOMEL_ERR_NULL;
+    if (b->io32 != io32) return GOMEL_ERR_BAD_CONFIG;
     gomel_handle* h = b->h;
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
@@ -913,10 +952,10 @@ static int batch_download_guarded(gomel_batch* b, double* const* out, const size
         if (out_cap && out_cap[u] < (size_t)b->utts[u].len) return GOMEL_ERR_BUFFER_TOO_SMALL;
     }
     PinnedScope pins;
-    for (size_t u = 0; u < b->n_utt; u++) pins.want(out[u], (size_t)b->utts[u].len * 8);
+    for (size_t u = 0; u < b->n_utt; u++) pins.want(out[u], (size_t)b->utts[u].len * b->esz);
     pins.commit(h->stream);
     for (size_t u = 0; u < b->n_utt; u++)
-        HIPCHK(hipMemcpyAsync(out[u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->stream));
+        HIPCHK(hipMemcpyAsync(out[u], (char*)b->d_out + (size_t)b->utts[u].xoff * b->esz, (size_t)b->utts[u].len * b->esz, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return GOMEL_OK;
 }
@@ -930,13 +969,16 @@ int gomel_batch_destroy(gomel_batch* b) {
     return GOMEL_OK;
 }
 
-// Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances: chunk i computes on the
-// compute stream while chunk i-1's waveforms go back over PCIe on the copy stream (all caller buffers pinned for the call).
-static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
-                         const uint64_t* seeds, double* const* out, const size_t* out_cap) {
+// Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances and pipelined over three
+// streams: chunk c+1's log-mel goes up (up_stream) while chunk c computes (stream) and chunk c-1's waveforms come down
+// (copy_stream); PCIe is full duplex, so with pinned host buffers the wall time is the compute time plus the first upload and
+// the last download.  Caller buffers that are not already pinned (gomel_host_alloc / gomel_host_register) are pinned for the call.
+static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
+                                  const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
     if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
     const int K = h->cfg.num_mels;
+    const size_t esz = io32 ? 4 : 8;
     int64_t total_frames = 0;
     for (size_t u = 0; u < n_utt; u++) {
         if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
@@ -946,9 +988,10 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* c
         if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
         total_frames += (int64_t)(n_pairs[u] / (size_t)K);
     }
-    // chunk plan: at least ~16k frames per chunk (enough to fill the chip), at most 8 chunks
-    const int64_t kMinChunkFrames = 16384;
+    // chunk plan: at least ~12k frames per chunk (enough to fill the chip several times over), at most 8 chunks
+    const int64_t kMinChunkFrames = 12288;
     int n_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(1, total_frames / kMinChunkFrames));
+    if (const char* e = getenv("GOMEL_CHUNKS")) { int v = atoi(e); if (v > 0) n_chunks = std::min(v, 64); }   // tuning knob
     n_chunks = (int)std::min<size_t>((size_t)n_chunks, n_utt);
     std::vector<size_t> bounds(1, 0);
     {
@@ -970,37 +1013,94 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* c
     std::vector<gomel_batch*>& chunks = chunk_list.v;
     chunks.assign((size_t)n_chunks, nullptr);
     int rc = GOMEL_OK;
-    for (int c = 0; c < n_chunks && !rc; c++) rc = gomel_batch_create(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], &chunks[c]);
+    for (int c = 0; c < n_chunks && !rc; c++) rc = batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c]);
     if (!rc) {
         std::lock_guard<std::mutex> lk(h->mu);
         DeviceGuard dg(h->device);
         if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
         PinnedScope pins;
-        std::vector<hipEvent_t> done((size_t)n_chunks, nullptr);
+        std::vector<hipEvent_t> done((size_t)n_chunks, nullptr), up((size_t)n_chunks, nullptr);
         for (size_t u = 0; u < n_utt && !rc; u++) {
-            pins.want(mel[u], n_pairs[u] * 16);
-            pins.want(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
-            if (x0 && x0[u]) pins.want(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * 8);
+            pins.want(mel[u], n_pairs[u] * 2 * esz);
+            pins.want(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * esz);
+            if (x0 && x0[u]) pins.want(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * esz);
         }
         pins.commit(h->stream, h->copy_stream);
+        for (int c = 0; c < n_chunks && !rc; c++)
+            if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&up[c], hipEventDisableTiming) != hipSuccess) rc = GOMEL_ERR_HIP;
+        std::vector<std::vector<uint64_t>> gseeds((size_t)n_chunks);   // default seed = GLOBAL utterance index, whatever the chunking
+        auto upload = [&](int c) {
+            gomel_batch* b = chunks[c];
+            const size_t u0 = bounds[c];
+            if (!seeds) { gseeds[c].resize(b->n_utt); for (size_t u = 0; u < b->n_utt; u++) gseeds[c][u] = (uint64_t)(u0 + u); }
+            int r = batch_upload_impl(b, mel + u0, x0 ? x0 + u0 : nullptr, seeds ? seeds + u0 : gseeds[c].data(), false, false, h->up_stream);
+            if (!r && hipEventRecord(up[c], h->up_stream) != hipSuccess) r = GOMEL_ERR_HIP;
+            return r;
+        };
+        if (!rc) rc = upload(0);
         for (int c = 0; c < n_chunks && !rc; c++) {
             gomel_batch* b = chunks[c];
             const size_t u0 = bounds[c];
-            std::vector<uint64_t> gseeds;                      // default seed = GLOBAL utterance index, whatever the chunking
-            if (!seeds) { gseeds.resize(b->n_utt); for (size_t u = 0; u < b->n_utt; u++) gseeds[u] = (uint64_t)(u0 + u); }
-            rc = batch_upload_impl(b, mel + u0, x0 ? x0 + u0 : nullptr, seeds ? seeds + u0 : gseeds.data(), false, false);
+            if (c + 1 < n_chunks) rc = upload(c + 1);                                   // queued before this chunk's kernels: runs beside them
+            if (!rc && hipStreamWaitEvent(h->stream, up[c], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
             if (!rc) rc = batch_run_impl(b, nullptr);
-            if (!rc && (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(done[c], h->stream) != hipSuccess ||
-                        hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+            if (!rc && (hipEventRecord(done[c], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
             for (size_t u = 0; u < b->n_utt && !rc; u++)
-                if (hipMemcpyAsync(out[u0 + u], b->d_out + b->utts[u].xoff, (size_t)b->utts[u].len * 8, hipMemcpyDefault, h->copy_stream) != hipSuccess)
+                if (hipMemcpyAsync(out[u0 + u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess)
                     rc = GOMEL_ERR_HIP;
         }
-        if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
+        if (hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
         if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
         for (hipEvent_t e : done) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : up) if (e) hipEventDestroy(e);
     }
     return rc;
+}
+
+// One call, several GPUs: contiguous utterance shards balanced by frame count, one host thread per handle (a handle = one
+// device), no data-path collective.  What a Go host uses to drive the 8 GPUs of a node without Python; every
+// handle must have been created from the same configuration (use gomel_create_from_tables for bit-identical tables).
+static int from_mel_batch_multi_guarded(gomel_handle* const* hs, size_t n_handles, size_t n_utt, const void* const* mel, const size_t* n_pairs,
+                                        const void* const* x0, const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
+    if (!hs || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
+    if (n_handles == 0 || n_utt == 0) return GOMEL_ERR_EMPTY;
+    for (size_t i = 0; i < n_handles; i++) {
+        if (!hs[i]) return GOMEL_ERR_NULL;
+        const gomel_config &a = hs[0]->cfg, &c = hs[i]->cfg;
+        if (a.num_mels != c.num_mels || a.window != c.window || a.resolut != c.resolut || a.griffin_lim_iterations != c.griffin_lim_iterations ||
+            a.mel_fmin != c.mel_fmin || a.mel_fmax != c.mel_fmax || a.tune_mul != c.tune_mul || a.tune_add != c.tune_add) return GOMEL_ERR_BAD_CONFIG;
+    }
+    const int K = hs[0]->cfg.num_mels;
+    std::vector<int64_t> pre(n_utt + 1, 0);
+    for (size_t u = 0; u < n_utt; u++) {
+        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
+        if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
+        pre[u + 1] = pre[u] + (int64_t)(n_pairs[u] / (size_t)K);
+    }
+    std::vector<size_t> bounds(n_handles + 1, 0);
+    for (size_t r = 1; r < n_handles; r++) {   // greedy on the prefix sum, as gomel_amd.dist.shard_bounds
+        const double target = (double)pre[n_utt] * (double)r / (double)n_handles;
+        size_t i = (size_t)(std::lower_bound(pre.begin(), pre.end(), (int64_t)std::ceil(target)) - pre.begin());
+        if (i > 0 && std::fabs((double)pre[i - 1] - target) <= std::fabs((double)pre[std::min(i, n_utt)] - target)) i--;
+        bounds[r] = std::min(std::max(i, bounds[r - 1]), n_utt);
+    }
+    bounds[n_handles] = n_utt;
+    std::vector<uint64_t> gseeds;
+    if (!seeds) { gseeds.resize(n_utt); for (size_t u = 0; u < n_utt; u++) gseeds[u] = (uint64_t)u; seeds = gseeds.data(); }   // global index: sharding does not change results
+    std::vector<int> rcs(n_handles, GOMEL_OK);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < n_handles; r++) {
+        const size_t lo = bounds[r], hi = bounds[r + 1];
+        if (hi <= lo) continue;
+        th.emplace_back([&, r, lo, hi] {
+            try {
+                rcs[r] = from_mel_batch_guarded(hs[r], hi - lo, mel + lo, n_pairs + lo, x0 ? x0 + lo : nullptr, seeds + lo, out + lo, out_cap ? out_cap + lo : nullptr, io32);
+            } catch (...) { rcs[r] = GOMEL_ERR_NO_MEMORY; }
+        });
+    }
+    for (std::thread& t : th) t.join();
+    for (int r : rcs) if (r) return r;
+    return GOMEL_OK;
 }
 
 int gomel_from_mel(gomel_handle* h, const double* mel, size_t n_pairs, const double* x0, uint64_t seed, double* out, size_t out_cap,
@@ -1018,25 +1118,35 @@ int gomel_from_mel(gomel_handle* h, const double* mel, size_t n_pairs, const dou
     return rc;
 }
 
-// ISTFT as an entry point of its own: Griffin-Lim from linear magnitudes, `iterations` = numIterations.
+// ISTFT as an entry point of its own: Griffin-Lim from linear magnitudes, `iterations` = numIterations.  With `spec_out` the
+// call also reproduces the reference's side effect on its spectrogram argument (mel/mel.go:98-108), bins 0 ... N/2.
 static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,
-                         double* out, size_t out_cap, size_t* out_len) {
+                         double* out, size_t out_cap, size_t* out_len, double* spec_out) {
     if (!h || !mags || !out) return GOMEL_ERR_NULL;
     if (n_frames == 0) return GOMEL_ERR_EMPTY;
     if (iterations < 0) return GOMEL_ERR_BAD_CONFIG;
     const size_t L = (size_t)h->cfg.resolut + (n_frames - 1) * (size_t)h->cfg.window;   // mel/mel.go:80
     if (out_cap < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
     gomel_batch* b = nullptr;
-    int rc = batch_create_common(h, 1, &n_frames, 1, iterations, &b);
+    const bool spec = spec_out && iterations > 0;   // zero iterations: the loop never runs, the spectrogram is left as it was
+    int rc = batch_create_common(h, 1, &n_frames, BF_DIRECT | (spec ? BF_SPEC : 0), iterations, &b);
     if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(h->mu);
         DeviceGuard dg(h->device);
         if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
-        const double* ins[1] = {mags};
-        const double* x0s[1] = {x0};
-        if (!rc) rc = batch_upload_impl(b, ins, x0s, &seed, true, true);
+        const void* ins[1] = {mags};
+        const void* x0s[1] = {x0};
+        if (!rc) rc = batch_upload_impl(b, ins, x0s, &seed, true, true, h->stream);
         if (!rc) rc = batch_run_impl(b, nullptr);
+        if (!rc && spec) {
+            const size_t bytes = n_frames * (size_t)(h->cfg.resolut / 2 + 1) * 16;
+            PinnedScope pins;
+            pins.want(spec_out, bytes); pins.commit(h->stream);
+            if (hipMemcpyAsync(spec_out, b->d_spec, bytes, hipMemcpyDefault, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+                g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
+            }
+        }
     }
     double* outs[1] = {out};
     if (!rc) rc = gomel_batch_download(b, outs, &out_cap);
@@ -1091,39 +1201,71 @@ size_t gomel_to_mel_pairs(const gomel_config* c, size_t n) {
     return (size_t)F * (size_t)c->num_mels;
 }
 
-static int to_mel_guarded(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
-    if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
+// (*Mel).ToMel for many waveforms in one go: every utterance padded as mel/impl.go:429-455 does, all frames through one STFT
+// launch and one domel launch, log-mel pairs back per utterance.  The single-utterance entry point is the n_utt = 1 case.
+static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* const* wave, const size_t* n_samples, double* const* out_pairs,
+                                const size_t* cap_pairs, size_t* n_pairs_out) {
+    if (!h || !wave || !n_samples || !out_pairs) return GOMEL_ERR_NULL;
+    if (n_utt == 0) return GOMEL_ERR_EMPTY;
     const gomel_config& c = h->cfg;
     const int N = c.resolut, H = N / 2, K = c.num_mels, hop = c.window;
-    if (n == 0) return GOMEL_ERR_EMPTY;
     if (h->dom_status) return h->dom_status;
-    const size_t P = gomel_pad_len(n, hop);                                   // pad, mel/impl.go:429-455
-    if (P < (size_t)N) return GOMEL_ERR_TOO_SHORT;
-    const size_t pairs = gomel_to_mel_pairs(&c, n), F = pairs / (size_t)K;    // gossp NumFrames
-    if (cap_pairs < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    std::vector<size_t> P(n_utt), F(n_utt), woff(n_utt), foff(n_utt);
+    size_t tot_w = 0, tot_f = 0;
+    for (size_t u = 0; u < n_utt; u++) {
+        if (!wave[u] || !out_pairs[u]) return GOMEL_ERR_NULL;
+        if (n_samples[u] == 0) return GOMEL_ERR_EMPTY;
+        P[u] = gomel_pad_len(n_samples[u], hop);                                  // pad, mel/impl.go:429-455
+        if (P[u] < (size_t)N) return GOMEL_ERR_TOO_SHORT;
+        const size_t pairs = gomel_to_mel_pairs(&c, n_samples[u]);                // gossp NumFrames * NumMels
+        F[u] = pairs / (size_t)K;
+        if (cap_pairs && cap_pairs[u] < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
+        woff[u] = tot_w; foff[u] = tot_f;
+        tot_w += (P[u] + 1) & ~(size_t)1;                                         // 16-byte aligned starts (double2 loads)
+        tot_f += F[u];
+    }
+    std::vector<int64_t> fx(tot_f);
+    for (size_t u = 0; u < n_utt; u++)
+        for (size_t f = 0; f < F[u]; f++) fx[foff[u] + f] = (int64_t)(woff[u] + f * (size_t)hop);
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
     double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
+    int64_t* d_fx = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;                      // big caller buffers: pinned for the call (pageable copies run at a tenth of the rate)
-    pins.want(wave, n * 8);
-    pins.want(out_pairs, pairs * 16);
+    for (size_t u = 0; u < n_utt; u++) { pins.want(wave[u], n_samples[u] * 8); pins.want(out_pairs[u], F[u] * (size_t)K * 16); }
     pins.commit(h->stream);
-    if (h->pool.alloc((void**)&d_wave, P * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, F * (size_t)(H + 1) * 8) != hipSuccess ||
-        h->pool.alloc((void**)&d_out, pairs * 16) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
-    if (!rc && (hipMemsetAsync(d_wave, 0, P * 8, h->stream) != hipSuccess ||
-                hipMemcpyAsync(d_wave, wave, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = GOMEL_ERR_HIP;
+    if (h->pool.alloc((void**)&d_wave, tot_w * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, tot_f * (size_t)(H + 1) * 8) != hipSuccess ||
+        h->pool.alloc((void**)&d_out, tot_f * (size_t)K * 16) != hipSuccess || h->pool.alloc((void**)&d_fx, tot_f * 8) != hipSuccess) {
+        g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
+    }
+    if (!rc && hipMemsetAsync(d_wave, 0, tot_w * 8, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    for (size_t u = 0; u < n_utt && !rc; u++)
+        if (hipMemcpyAsync(d_wave + woff[u], wave[u], n_samples[u] * 8, hipMemcpyDefault, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc && hipMemcpyAsync(d_fx, fx.data(), tot_f * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
         GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
-                              hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((F + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_smag, (int64_t)F, hop, h->dt); });
-        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)F), dim3(256), 0, h->stream, d_smag, h->dt.dom, d_out, K, H);
-        if (hipMemcpyAsync(out_pairs, d_out, pairs * 16, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-            hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
+                              hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((tot_f + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_fx, d_smag, (int64_t)tot_f, hop, h->dt); });
+        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)tot_f), dim3(256), 0, h->stream, d_smag, h->dt.dom, d_out, K, H);
+        for (size_t u = 0; u < n_utt && !rc; u++)
+            if (hipMemcpyAsync(out_pairs[u], d_out + foff[u] * (size_t)K * 2, F[u] * (size_t)K * 16, hipMemcpyDefault, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;   // also: fx must outlive its copy
+        if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
     }
     if (d_wave) h->pool.release(d_wave);
     if (d_smag) h->pool.release(d_smag);
     if (d_out) h->pool.release(d_out);
-    if (!rc && n_pairs) *n_pairs = pairs;
+    if (d_fx) h->pool.release(d_fx);
+    if (!rc && n_pairs_out) for (size_t u = 0; u < n_utt; u++) n_pairs_out[u] = F[u] * (size_t)K;
+    return rc;
+}
+
+static int to_mel_guarded(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
+    if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
+    if (n == 0) return GOMEL_ERR_EMPTY;
+    size_t got = 0;
+    const int rc = to_mel_batch_guarded(h, 1, &wave, &n, &out_pairs, &cap_pairs, &got);
+    if (!rc && n_pairs) *n_pairs = got;
     return rc;
 }
 
@@ -1229,6 +1371,27 @@ int gomel_debug_stamps(unsigned long long* out21, int clear) {
 }
 #endif
 
+// ---- host memory helpers: pinned buffers a bulk caller reuses across calls (no per-call hipHostRegister)
+void* gomel_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+int gomel_host_free(void* p) {
+    if (!p) return GOMEL_OK;
+    HIPCHK(hipHostFree(p));
+    return GOMEL_OK;
+}
+int gomel_host_register(void* p, size_t bytes) {   // keeps the range pinned until gomel_host_unregister (reference-counted with the per-call pins)
+    if (!p || bytes == 0) return GOMEL_ERR_NULL;
+    return g_pins.acquire(p, bytes) ? GOMEL_OK : GOMEL_ERR_HIP;
+}
+int gomel_host_unregister(void* p) {
+    if (!p) return GOMEL_ERR_NULL;
+    g_pins.release((uintptr_t)p);
+    return GOMEL_OK;
+}
+
 // ---- exception firewall: the entry points that allocate on the host
 int gomel_set_window(gomel_handle* h, const double* w, size_t n) {
     GOMEL_TRY return set_window_guarded(h, w, n); GOMEL_CATCH
@@ -1236,8 +1399,14 @@ int gomel_set_window(gomel_handle* h, const double* w, size_t n) {
 int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
     GOMEL_TRY return batch_create_guarded(h, n_utt, n_pairs, out); GOMEL_CATCH
 }
+int gomel_batch_create_f32(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out) {
+    GOMEL_TRY return batch_create_f32_guarded(h, n_utt, n_pairs, out); GOMEL_CATCH
+}
 int gomel_batch_upload(gomel_batch* b, const double* const* mel, const double* const* x0, const uint64_t* seeds) {
-    GOMEL_TRY return batch_upload_guarded(b, mel, x0, seeds); GOMEL_CATCH
+    GOMEL_TRY return batch_upload_guarded(b, (const void* const*)mel, (const void* const*)x0, seeds, 0); GOMEL_CATCH
+}
+int gomel_batch_upload_f32(gomel_batch* b, const float* const* mel, const float* const* x0, const uint64_t* seeds) {
+    GOMEL_TRY return batch_upload_guarded(b, (const void* const*)mel, (const void* const*)x0, seeds, 1); GOMEL_CATCH
 }
 int gomel_batch_run(gomel_batch* b) {
     GOMEL_TRY return batch_run_guarded(b); GOMEL_CATCH
@@ -1246,11 +1415,22 @@ int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t) {
     GOMEL_TRY return batch_run_timed_guarded(b, t); GOMEL_CATCH
 }
 int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap) {
-    GOMEL_TRY return batch_download_guarded(b, out, out_cap); GOMEL_CATCH
+    GOMEL_TRY return batch_download_guarded(b, (void* const*)out, out_cap, 0); GOMEL_CATCH
+}
+int gomel_batch_download_f32(gomel_batch* b, float* const* out, const size_t* out_cap) {
+    GOMEL_TRY return batch_download_guarded(b, (void* const*)out, out_cap, 1); GOMEL_CATCH
 }
 int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
                          const uint64_t* seeds, double* const* out, const size_t* out_cap) {
-    GOMEL_TRY return from_mel_batch_guarded(h, n_utt, mel, n_pairs, x0, seeds, out, out_cap); GOMEL_CATCH
+    GOMEL_TRY return from_mel_batch_guarded(h, n_utt, (const void* const*)mel, n_pairs, (const void* const*)x0, seeds, (void* const*)out, out_cap, 0); GOMEL_CATCH
+}
+int gomel_from_mel_batch_f32(gomel_handle* h, size_t n_utt, const float* const* mel, const size_t* n_pairs, const float* const* x0,
+                             const uint64_t* seeds, float* const* out, const size_t* out_cap) {
+    GOMEL_TRY return from_mel_batch_guarded(h, n_utt, (const void* const*)mel, n_pairs, (const void* const*)x0, seeds, (void* const*)out, out_cap, 1); GOMEL_CATCH
+}
+int gomel_from_mel_batch_multi(gomel_handle* const* handles, size_t n_handles, size_t n_utt, const double* const* mel, const size_t* n_pairs,
+                               const double* const* x0, const uint64_t* seeds, double* const* out, const size_t* out_cap) {
+    GOMEL_TRY return from_mel_batch_multi_guarded(handles, n_handles, n_utt, (const void* const*)mel, n_pairs, (const void* const*)x0, seeds, (void* const*)out, out_cap, 0); GOMEL_CATCH
 }
 int gomel_target_magnitudes(gomel_handle* h, const double* mel, size_t n_pairs, float* mag_out) {
     GOMEL_TRY return target_magnitudes_guarded(h, mel, n_pairs, mag_out); GOMEL_CATCH
@@ -1261,10 +1441,18 @@ int gomel_from_phase(gomel_handle* h, int32_t num_freqs, double volume_boost, co
 }
 int gomel_istft(gomel_handle* h, const double* mags, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed, double* out,
                 size_t out_cap, size_t* out_len) {
-    GOMEL_TRY return istft_guarded(h, mags, n_frames, iterations, x0, seed, out, out_cap, out_len); GOMEL_CATCH
+    GOMEL_TRY return istft_guarded(h, mags, n_frames, iterations, x0, seed, out, out_cap, out_len, nullptr); GOMEL_CATCH
+}
+int gomel_istft_spec(gomel_handle* h, const double* mags, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed, double* out,
+                     size_t out_cap, size_t* out_len, double* spec_out) {
+    GOMEL_TRY return istft_guarded(h, mags, n_frames, iterations, x0, seed, out, out_cap, out_len, spec_out); GOMEL_CATCH
 }
 int gomel_to_mel(gomel_handle* h, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
     GOMEL_TRY return to_mel_guarded(h, wave, n, out_pairs, cap_pairs, n_pairs); GOMEL_CATCH
+}
+int gomel_to_mel_batch(gomel_handle* h, size_t n_utt, const double* const* wave, const size_t* n_samples, double* const* out_pairs,
+                       const size_t* cap_pairs, size_t* n_pairs_out) {
+    GOMEL_TRY return to_mel_batch_guarded(h, n_utt, wave, n_samples, out_pairs, cap_pairs, n_pairs_out); GOMEL_CATCH
 }
 int gomel_to_phase(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
     GOMEL_TRY return to_phase_guarded(h, num_freqs, wave, n, out_pairs, cap_pairs, n_pairs); GOMEL_CATCH

@@ -114,8 +114,10 @@ class Engine:
                                out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_from_mel")
         return out[:got.value]
 
-    def istft(self, magnitudes, iterations, x0=None, seed=0):
-        """gomel_istft: Griffin-Lim from linear magnitudes [F][N/2+1] (the reference's exported ISTFT, mel/mel.go:76-139)."""
+    def istft(self, magnitudes, iterations, x0=None, seed=0, spec=False):
+        """gomel_istft: Griffin-Lim from linear magnitudes [F][N/2+1] (the reference's exported ISTFT, mel/mel.go:76-139).
+        With spec=True (gomel_istft_spec) also returns what the reference leaves in its spectrogram argument, bins 0..N/2
+        (complex [F][N/2+1]; None when iterations == 0: the reference's loop does not run)."""
         m = np.ascontiguousarray(magnitudes, dtype=np.float64)
         H1 = self.cfg.resolut // 2 + 1
         if m.ndim != 2 or m.shape[1] != H1:
@@ -130,9 +132,41 @@ class Engine:
                 raise ValueError("x0 must have length %d" % n)
             x0p = x0.ctypes.data_as(c_double_p)
         got = ctypes.c_size_t(0)
-        check(_lib.lib().gomel_istft(self._h, m.ctypes.data_as(c_double_p), F, int(iterations), x0p, ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                     out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_istft")
-        return out[:got.value]
+        if not spec:
+            check(_lib.lib().gomel_istft(self._h, m.ctypes.data_as(c_double_p), F, int(iterations), x0p, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                         out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got)), "gomel_istft")
+            return out[:got.value]
+        sp = np.zeros((max(F, 1), H1, 2), dtype=np.float64)
+        check(_lib.lib().gomel_istft_spec(self._h, m.ctypes.data_as(c_double_p), F, int(iterations), x0p, ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                          out.ctypes.data_as(c_double_p), out.size, ctypes.byref(got), sp.ctypes.data_as(c_double_p)), "gomel_istft_spec")
+        return out[:got.value], (None if int(iterations) == 0 else sp[:F, :, 0] + 1j * sp[:F, :, 1])
+
+    def from_mel_batch_f32(self, mels, x0s=None, seeds=None, outs=None):
+        """gomel_from_mel_batch_f32: float32 log-mel pairs in, float32 waveforms out (half the PCIe bytes of the float64 call)."""
+        ms = [np.ascontiguousarray(m, dtype=np.float32) for m in mels]
+        n = len(ms)
+        if n == 0:
+            return []
+        if any(m.ndim != 2 or m.shape[1] != 2 for m in ms):
+            raise ValueError("expected [n, 2] arrays")
+        lens = [self.out_len(len(m)) for m in ms]
+        if outs is None:
+            outs = [np.empty(max(L, 1), dtype=np.float32) for L in lens]
+        elif len(outs) != n or any(o.dtype != np.float32 or o.ndim != 1 or len(o) < L or not o.flags.c_contiguous for o, L in zip(outs, lens)):
+            raise ValueError("outs must be C-contiguous float32 arrays of at least the output lengths")
+        xs = None
+        if x0s is not None:
+            xs = [None if x is None else np.ascontiguousarray(x, dtype=np.float32) for x in x0s]
+        fpp = ctypes.POINTER(_lib.c_float_p)
+        mp = (_lib.c_float_p * n)(*[m.ctypes.data_as(_lib.c_float_p) for m in ms])
+        op = (_lib.c_float_p * n)(*[o.ctypes.data_as(_lib.c_float_p) for o in outs])
+        xp = None if xs is None else (_lib.c_float_p * n)(*[None if x is None else x.ctypes.data_as(_lib.c_float_p) for x in xs])
+        sp = None if seeds is None else (ctypes.c_uint64 * n)(*[int(s) & (2 ** 64 - 1) for s in seeds])
+        npairs = (ctypes.c_size_t * n)(*[len(m) for m in ms])
+        caps = (ctypes.c_size_t * n)(*[len(o) for o in outs])
+        check(_lib.lib().gomel_from_mel_batch_f32(self._h, n, ctypes.cast(mp, fpp), npairs, None if xp is None else ctypes.cast(xp, fpp), sp,
+                                                  ctypes.cast(op, fpp), caps), "gomel_from_mel_batch_f32")
+        return [o[:L] for o, L in zip(outs, lens)]
 
     def from_mel_batch(self, mels, x0s=None, seeds=None, outs=None):
         """gomel_from_mel_batch: host buffers in, host buffers out (chunked, copy/compute overlapped inside the library).
@@ -181,6 +215,24 @@ class Engine:
         got = ctypes.c_size_t(0)
         check(L.gomel_to_mel(self._h, w.ctypes.data_as(c_double_p), w.size, out.ctypes.data_as(c_double_p), cap, ctypes.byref(got)), "gomel_to_mel")
         return out[:got.value]
+
+    def to_mel_batch(self, waves):
+        """gomel_to_mel_batch: many independent ToMel calls in one go (one STFT launch, one domel launch over all frames)."""
+        ws = [np.ascontiguousarray(w, dtype=np.float64) for w in waves]
+        n = len(ws)
+        if n == 0:
+            return []
+        L = _lib.lib()
+        caps = [L.gomel_to_mel_pairs(ctypes.byref(self.cfg), w.size) for w in ws]
+        outs = [np.empty((max(c, 1), 2), dtype=np.float64) for c in caps]
+        dpp = ctypes.POINTER(c_double_p)
+        wp = (c_double_p * n)(*[w.ctypes.data_as(c_double_p) for w in ws])
+        op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
+        ns = (ctypes.c_size_t * n)(*[w.size for w in ws])
+        cp = (ctypes.c_size_t * n)(*caps)
+        got = (ctypes.c_size_t * n)()
+        check(L.gomel_to_mel_batch(self._h, n, ctypes.cast(wp, dpp), ns, ctypes.cast(op, dpp), cp, got), "gomel_to_mel_batch")
+        return [o[:g] for o, g in zip(outs, got)]
 
     # -- FFT test hooks ------------------------------------------------------------------------------
     def rfft_frames(self, frames):
@@ -316,8 +368,10 @@ class Mel:
                c.device, c.hann_periodic)
         e = self._engines.get(key)
         if e is None:
+            for old in self._engines.values():
+                old.close()           # one live handle per Mel object: the one being replaced is released now, not at GC time
             e = Engine(c)
-            self._engines = {key: e}  # one live handle per Mel object
+            self._engines = {key: e}
             e._precision = 32
         if e._precision != int(self.Precision):
             e.set_precision(int(self.Precision))
@@ -337,6 +391,9 @@ class Mel:
         wave = self.engine().from_mel(ospectrum, x0=x0, seed=seed)
         np.exp(ospectrum, out=ospectrum)  # spectral_denormalize side effect on the caller's slice (mel/mel.go:143)
         return wave
+
+    def ToMelBatch(self, bufs):
+        return self.engine().to_mel_batch(bufs)
 
     def FromMelBatch(self, spectra, x0s=None, seeds=None):
         outs = self.engine().from_mel_batch(spectra, x0s, seeds)
@@ -377,6 +434,57 @@ class Mel:
         return None
 
 
+class _PinnedOwner:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().gomel_host_free(ctypes.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def host_alloc(shape, dtype=np.float64):
+    """A numpy array in pinned host memory (gomel_host_alloc): buffers a bulk caller reuses across gomel_from_mel_batch calls, so
+    that no call pays hipHostRegister.  Freed with the array."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    ptr = _lib.lib().gomel_host_alloc(max(n, 1) * dt.itemsize)
+    if not ptr:
+        raise MemoryError("gomel_host_alloc(%d bytes) failed" % (n * dt.itemsize))
+    owner = _PinnedOwner(ptr)
+    buf = (ctypes.c_char * (max(n, 1) * dt.itemsize)).from_address(ptr)
+    buf._owner = owner                       # the ctypes view keeps the allocation alive; numpy keeps the view alive
+    a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    return a
+
+
+def from_mel_batch_multi(engines, mels, x0s=None, seeds=None, outs=None):
+    """gomel_from_mel_batch_multi: one call over several handles (one per GPU): contiguous utterance shards balanced by frame
+    count, one host thread per device inside the library, no collective."""
+    e0 = engines[0]
+    ms = [_as_pairs(m) for m in mels]
+    n = len(ms)
+    lens = [e0.out_len(len(m)) for m in ms]
+    if outs is None:
+        outs = [np.empty(max(L, 1), dtype=np.float64) for L in lens]
+    xs = None if x0s is None else [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in x0s]
+    dpp = ctypes.POINTER(c_double_p)
+    hp = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    mp = (c_double_p * n)(*[m.ctypes.data_as(c_double_p) for m in ms])
+    op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
+    xp = None if xs is None else (c_double_p * n)(*[None if x is None else x.ctypes.data_as(c_double_p) for x in xs])
+    sp = None if seeds is None else (ctypes.c_uint64 * n)(*[int(s) & (2 ** 64 - 1) for s in seeds])
+    npairs = (ctypes.c_size_t * n)(*[len(m) for m in ms])
+    caps = (ctypes.c_size_t * n)(*[len(o) for o in outs])
+    check(_lib.lib().gomel_from_mel_batch_multi(hp, len(engines), n, ctypes.cast(mp, dpp), npairs, None if xp is None else ctypes.cast(xp, dpp), sp,
+                                                ctypes.cast(op, dpp), caps), "gomel_from_mel_batch_multi")
+    return [o[:L] for o, L in zip(outs, lens)]
+
+
 def build_tables(cfg):
     """gomel_tables_build: the table blob (Hann, undomel rows, domel rows) from a configuration, on the host alone -- no GPU
     is touched.  The same bytes `Engine.export_tables()` returns for a handle of that configuration."""
@@ -393,8 +501,9 @@ def ISTFT(s, spectrogram, numIterations, x0=None, seed=None, device=-1):
     `s` is anything with the two fields of gossp's STFT the reference reads: `FrameShift` (hop) and `Window` (frameLen
     doubles).  `spectrogram` is [F][frameLen] complex (or real magnitudes); as in the reference only |spectrogram[f][j]|,
     j <= frameLen/2, matter.  The initial signal is `x0`, or the documented SplitMix64 stream of `seed`, or (neither given)
-    Python's `random`, where the reference draws from math/rand.  Unlike the reference the caller's spectrogram is left
-    untouched (the reference overwrites it with the last phase estimate)."""
+    Python's `random`, where the reference draws from math/rand.  As in the reference (mel/mel.go:98-108) a complex128 numpy
+    `spectrogram` is overwritten with the last iteration's phase estimate on its own magnitudes (lower half + conjugate fill);
+    other inputs (lists, real arrays) cannot be written to and are left alone."""
     spec = np.asarray(spectrogram)
     if spec.ndim != 2 or spec.shape[0] == 0:
         raise GomelError(4, "ISTFT")          # the reference panics on spectrogram[0] (mel/mel.go:78)
@@ -410,7 +519,14 @@ def ISTFT(s, spectrogram, numIterations, x0=None, seed=None, device=-1):
         e.set_window(window)
         if x0 is None and seed is None:
             seed = random.getrandbits(64)
-        return e.istft(np.abs(spec[:, :N // 2 + 1]), numIterations, x0=x0, seed=seed or 0)
+        writable = isinstance(spectrogram, np.ndarray) and spectrogram.dtype == np.complex128 and spectrogram.flags.writeable
+        if not writable or int(numIterations) == 0:
+            return e.istft(np.abs(spec[:, :N // 2 + 1]), numIterations, x0=x0, seed=seed or 0)
+        wave, sp = e.istft(np.abs(spec[:, :N // 2 + 1]), numIterations, x0=x0, seed=seed or 0, spec=True)
+        spectrogram[:, :N // 2 + 1] = sp                                   # mel/mel.go:98-102, bins 0 .. N/2
+        j = np.arange(1, N // 2)
+        spectrogram[:, N - j] = np.conj(spectrogram[:, j])                 # mel/mel.go:105-108
+        return wave
     finally:
         e.close()
 

@@ -16,7 +16,8 @@
  * keeps its spectrograms in HBM hands over device pointers; the copies are hipMemcpyDefault).  Everything else is host.
  *
  * Threading: a handle may be used from concurrent host threads; calls on one handle are serialised by an
- * internal mutex and every entry sets the HIP device of the handle on the calling thread.
+ * internal mutex; every entry switches the calling thread to the handle's HIP device and restores the thread's previous
+ * device before it returns (a process that drives several GPUs finds its current device unchanged).
  */
 #ifndef GOMEL_HIP_H
 #define GOMEL_HIP_H
@@ -28,12 +29,12 @@
 extern "C" {
 #endif
 
-#define GOMEL_HIP_ABI_VERSION 1
+#define GOMEL_HIP_ABI_VERSION 2
 
 typedef enum gomel_status {
     GOMEL_OK = 0,
     GOMEL_ERR_BAD_CONFIG = 1,     /* NumMels/Window/Resolut <= 0, TuneMul == 0, fmax+fmin <= 0 ...                 */
-    GOMEL_ERR_UNSUPPORTED_N = 2,  /* Resolut not in {256,...,4096 powers of 2} (reference: any N, Bluestein) */
+    GOMEL_ERR_UNSUPPORTED_N = 2,  /* Resolut outside what the FFT cores cover (see gomel_create)                   */
     GOMEL_ERR_BAD_LENGTH = 3,     /* n_pairs % NumMels != 0 (reference: index panic, mel/impl.go:366)             */
     GOMEL_ERR_EMPTY = 4,          /* zero frames (reference: index panic at mel/mel.go:78)                        */
     GOMEL_ERR_TABLE_RANGE = 5,    /* undomel/domel table indexes past the band/bin slice (reference: panic)       */
@@ -116,25 +117,57 @@ int gomel_from_mel(gomel_handle* h, const double* mel_pairs, size_t n_pairs, con
  * complex [F][N] argument it reads only |spectrogram[f][j]| for j <= N/2 (phases are re-estimated every iteration and the upper
  * half is conjugate-filled, mel.go:98-108), so the boundary takes those magnitudes: [n_frames][N/2+1] doubles (host or device).
  * Window and hop come from the handle (gomel_set_window injects s.Window); `iterations` = numIterations >= 0 replaces the
- * handle's GriffinLimIterations for this call.  x0 / seed / out as for gomel_from_mel.  The reference also leaves the updated
- * phases in the caller's spectrogram; that side effect is not reproduced. */
+ * handle's GriffinLimIterations for this call.  x0 / seed / out as for gomel_from_mel. */
 int gomel_istft(gomel_handle* h, const double* magnitudes, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,
                 double* out, size_t out_cap, size_t* out_len);
+/* The same with ISTFT's side effect on its argument (mel/mel.go:98-108: every iteration overwrites spectrogram[i][j] with
+ * Rect(Abs(spectrogram[i][j]), Phase(S[j])) and conjugate-fills the upper half): spec_out receives [n_frames][N/2+1][2] doubles,
+ * bins 0 ... N/2 of what the reference leaves in the caller's slice -- the last iteration's phase estimate on the caller's
+ * magnitudes; the Go shim writes them back and mirrors bins N/2+1 ... N-1 as conjugates.  Nothing is written when iterations == 0
+ * (the reference's loop does not run).  spec_out may be NULL (= gomel_istft).  Runs the generic kernels (any batch size). */
+int gomel_istft_spec(gomel_handle* h, const double* magnitudes, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,
+                     double* out, size_t out_cap, size_t* out_len, double* spec_out);
 
 /* Many independent FromMel calls in one go (utterances are independent: mel/mel.go:142-152 keeps no state).
  * x0 may be NULL, and so may any x0[u]; seeds may be NULL (then seed = u). */
 int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel_pairs, const size_t* n_pairs,
                          const double* const* x0, const uint64_t* seeds, double* const* out, const size_t* out_cap);
 
+/* fp32 host I/O: the same call for callers whose spectrograms and waveforms are float (an acoustic model's output,
+ * a float PCM sink): half the PCIe bytes.  The log-mel values are taken as given (converted to double on the device, then the
+ * fp64 table arithmetic of gomel_from_mel); the waveform is the fp32 result of the iteration without the final widening.
+ * Not available on a handle in 64-bit precision mode (GOMEL_ERR_BAD_CONFIG). */
+int gomel_from_mel_batch_f32(gomel_handle* h, size_t n_utt, const float* const* mel_pairs, const size_t* n_pairs,
+                             const float* const* x0, const uint64_t* seeds, float* const* out, const size_t* out_cap);
+
+/* One call, several GPUs of one node (SURVEY 8e "one host thread/stream per device"): `handles` holds one handle per device,
+ * all created from the same configuration (gomel_create_from_tables gives them bit-identical tables); the utterances are cut
+ * into contiguous shards balanced by frame count, each shard runs gomel_from_mel_batch on its handle from its own host thread.
+ * No collective on the data path; default seeds are the GLOBAL utterance indices, so results do not depend on the sharding. */
+int gomel_from_mel_batch_multi(gomel_handle* const* handles, size_t n_handles, size_t n_utt, const double* const* mel_pairs,
+                               const size_t* n_pairs, const double* const* x0, const uint64_t* seeds, double* const* out,
+                               const size_t* out_cap);
+
+/* Pinned host memory for bulk callers.  gomel_from_mel_batch and friends pin pageable caller buffers for the duration of a
+ * call (hipHostRegister: ~8 ms per GiB, every call); a caller that reuses its buffers allocates them here, or registers its
+ * own once, and pays nothing per call.  gomel_host_unregister takes the pointer that was registered. */
+void* gomel_host_alloc(size_t bytes);
+int gomel_host_free(void* p);
+int gomel_host_register(void* p, size_t bytes);
+int gomel_host_unregister(void* p);
+
 /* The same work split so that inputs can be resident in HBM before the clock starts (bench / pipelines):
  * create (plan + allocate) -> upload (H2D of log-mel and x0) -> run (all device work, asynchronous on the
  * handle's stream) -> download (D2H of the waveforms, synchronises). */
 int gomel_batch_create(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out);
+int gomel_batch_create_f32(gomel_handle* h, size_t n_utt, const size_t* n_pairs, gomel_batch** out); /* float log-mel / x0 / waveforms */
 int gomel_batch_upload(gomel_batch* b, const double* const* mel_pairs, const double* const* x0, const uint64_t* seeds);
+int gomel_batch_upload_f32(gomel_batch* b, const float* const* mel_pairs, const float* const* x0, const uint64_t* seeds);
 int gomel_batch_run(gomel_batch* b);
 int gomel_batch_run_timed(gomel_batch* b, gomel_timing* t); /* synchronises */
 int gomel_batch_sync(gomel_batch* b);
 int gomel_batch_download(gomel_batch* b, double* const* out, const size_t* out_cap);
+int gomel_batch_download_f32(gomel_batch* b, float* const* out, const size_t* out_cap);
 int gomel_batch_destroy(gomel_batch* b);
 /* 0 = let the library choose (fused kernel when the hop allows it and the batch is big enough to fill the chip: from 1.5 k
  * frames at Resolut 4096 to 12 k at 256, measured crossovers);
@@ -148,6 +181,10 @@ int gomel_set_precision(gomel_handle* h, int bits);
 size_t gomel_to_mel_pairs(const gomel_config* cfg, size_t n_samples);
 int gomel_to_mel(gomel_handle* h, const double* wave, size_t n_samples, double* out_pairs, size_t cap_pairs,
                  size_t* n_pairs);
+/* Many ToMel calls in one go (independent waveforms, mel/mel.go:46-74 keeps no state): one STFT launch and one domel launch over
+ * all frames -- what generates FromMel inputs at scale.  n_pairs_out[u] (may be NULL) receives len(ToMel(wave[u])). */
+int gomel_to_mel_batch(gomel_handle* h, size_t n_utt, const double* const* wave, const size_t* n_samples, double* const* out_pairs,
+                       const size_t* cap_pairs, size_t* n_pairs_out);
 
 /* Package phase (the reference's phase-preserving codec, phase/phase.go) on the same handle: the handle supplies Window, Resolut
  * and the Hann table; NumMels / MelFmax are not used.  NumFreqs and VolumeBoost are the fields of `type Phase` (phase.go:8-18).

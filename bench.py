@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- Griffin-Lim frames/s (4096-pt, 60 iters) on MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--parity all|sample|none] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with no launcher starts the N ranks itself (torch.distributed.run as a child process, before anything
+touches a GPU) and exits with its code.
 
-A "step" is one pass of the hot path over one batch: log-mel -> target magnitudes, x0 generation, all 60 Griffin-Lim
-iterations, float -> double output -- everything (*Mel).FromMel does (mel/mel.go:142-152) -- with the inputs (fp64
-log-mel as the API receives it) already resident in HBM and the output left in HBM.  Utterances are independent, so with
-N GPUs every rank runs its own shard of the same size (weak scaling) and there is no data-path collective; the only
-collective is the one-off broadcast of the table blob ("mel basis") from rank 0 over RCCL.
+METRIC (SURVEY 8d / BASELINE.md): frames/s = frames pushed through all 60 Griffin-Lim iterations / wall time of
+gomel_from_mel_batch -- host fp64 log-mel in, host fp64 waveforms out, H2D and D2H INCLUDED, handle creation excluded.  A "step" is
+one such call over the rank's batch; W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, MAX
+over ranks.  The caller's buffers are pinned host memory (gomel_host_alloc: what a bulk Go caller would hand over); the same call
+through pageable buffers is reported beside it (`pageable_frames_per_s`), and the HBM-resident rate -- inputs already in HBM, output
+left in HBM -- as `resident_frames_per_s`.  The roofline block is about the dominant kernel: its launch time comes from HIP events
+on the library's stream in this run, its algorithmic bytes from SURVEY 8(d).
 
-Workloads (BASELINE.json configs): cfg3 = configs[2], 256 x (192 mels x 400 frames) random log-mel, N 4096 / hop 1280,
-60 iterations (the configuration the HBM-roofline figure is quoted on; default).  cfg2 = configs[1], one 10 s utterance
-(342 frames) -- launch-latency bound, reported in the same JSON line as "single_utterance".  cfg4 = configs[3], the
-22.05 kHz TTS geometry (N 1024 / hop 256 / 80 mels).  cfg5 = configs[4], a fixed 8192-utterance corpus cut into one
-contiguous shard per rank (strong scaling; ~105 GB of HBM at N=1).
+Workloads (BASELINE.json configs): cfg3 = configs[2], 256 x (192 mels x 400 frames) random log-mel, N 4096 / hop 1280, 60
+iterations (the configuration the roofline figure is quoted on; default at N = 1, weak scaling when forced at N > 1).  cfg5 =
+configs[4], a FIXED corpus of 8192 such utterances cut into one contiguous shard per rank (strong scaling; default when N > 1); a
+rank materialises its shard as one 256-utterance host block that is re-used with the shard's own seeds (synthetic data), one call
+per block.  cfg2 = configs[1], one 10 s utterance (342 frames), also reported in every N = 1 line as `single_utterance`.  cfg4 =
+configs[3], the 22.05 kHz TTS geometry (N 1024 / hop 256 / 80 mels).  Utterances are independent: no data-path collective; the
+one collective is the broadcast of the table blob ("mel basis") from rank 0 over RCCL.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import math
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -31,19 +39,20 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
-    # name: (description, Mel fields, utterances per GPU, frames per utterance, sample rate)
+    # name: (description, Mel fields, utterances per GPU (corpus size when strong), frames per utterance, sample rate)
     "cfg3": ("configs[2]: 256 x (192 mels x 400 frames) random log-mel, N=4096 hop=1280, 60 GL iters",
              dict(NumMels=192, MelFmin=0.0, MelFmax=16000.0, Window=1280, Resolut=4096, GriffinLimIterations=60), 256, 400, 44100),
     "cfg2": ("configs[1]: single 10 s utterance @44.1kHz (342 frames), N=4096 hop=1280, 60 GL iters",
              dict(NumMels=192, MelFmin=0.0, MelFmax=16000.0, Window=1280, Resolut=4096, GriffinLimIterations=60), 1, 342, 44100),
     "cfg4": ("configs[3]: 256 x (80 mels x 400 frames), 22.05kHz TTS geometry N=1024 hop=256, 60 GL iters",
              dict(NumMels=80, MelFmin=0.0, MelFmax=8000.0, Window=256, Resolut=1024, GriffinLimIterations=60), 256, 400, 22050),
-    # configs[4]: a FIXED corpus of 8192 utterances cut into contiguous shards, one per rank (strong scaling; 8192/N per GPU)
     "cfg5": ("configs[4]: 8192-utterance corpus (192 mels x 400 frames each) sharded over the ranks, N=4096 hop=1280, 60 GL iters",
              dict(NumMels=192, MelFmin=0.0, MelFmax=16000.0, Window=1280, Resolut=4096, GriffinLimIterations=60), 8192, 400, 44100),
 }
 STRONG = {"cfg5"}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BLOCK = 256                     # utterances per gomel_from_mel_batch call
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
 def algorithmic_bytes_per_frame_iter(N, hop):
@@ -51,14 +60,10 @@ def algorithmic_bytes_per_frame_iter(N, hop):
     return hop * 4 + (N // 2 + 1) * 4 + hop * 4
 
 
-def make_inputs(fields, n_utt, frames, rank):
+def make_inputs(fields, n_utt, frames, first):
     """Config-3 style synthetic log-mel: iid U[ln 1e-5, ln 50], seed = global utterance index."""
     K = fields["NumMels"]
-    mels = []
-    for u in range(n_utt):
-        rng = np.random.default_rng(rank * n_utt + u)
-        mels.append(rng.uniform(math.log(1e-5), math.log(50.0), size=(frames * K, 2)))
-    return mels
+    return [np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(frames * K, 2)) for u in range(n_utt)]
 
 
 def build_engine(fields, device, tables=None):
@@ -67,54 +72,117 @@ def build_engine(fields, device, tables=None):
     for k, v in fields.items():
         setattr(m, k, v)
     m.Device = device
-    cfg = m._config()
-    return gomel_amd.Engine(cfg, tables=tables)
+    return gomel_amd.Engine(m._config(), tables=tables)
 
 
-def run_workload(engine, fields, n_utt, frames, rank, steps, warmup, barrier):
+def committed_traffic(workload, fast_path):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes (profiles/traffic.json): counters
+    cannot be read from inside the timed process, so this figure is a label from an earlier profile of the same kernel."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            e = json.load(f).get("%s:%s" % (workload, "fused" if fast_path else "generic"))
+        return (None, None) if e is None else (e.get("hbm_bytes_per_launch"), "profiles/traffic.json [%s] (separate rocprofv3 --pmc passes, not this run)" % e.get("from", "?"))
+    except (OSError, ValueError):
+        return None, None
+
+
+def host_cpus():
+    """Threads the CPU legs may use: the affinity mask, cut to the cgroup's CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = "affinity mask"
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max" and int(q) // int(p) >= 1 and int(q) // int(p) < n:
+            n, how = int(q) // int(p), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    return max(1, n), how
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def go_probe():
+    """say whether the box could time the Go reference at all."""
+    go = shutil.which("go")
+    if not go:
+        return "go: not found on PATH (the Go reference cannot be built or timed here; CPU legs are the C / NumPy restatements)"
+    try:
+        v = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as ex:  # noqa: BLE001
+        v = "go present but `go version` failed: %r" % (ex,)
+    return v + " (module cache for go-dsp / gossp still needed; not attempted)"
+
+
+# ------------------------------------------------------------------------------------------------ the measured legs
+def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier, pinned=True):
+    """The metric: K calls of gomel_from_mel_batch per BLOCK of the rank's shard, host buffers in, host buffers out."""
     import gomel_amd
     import torch
     K = fields["NumMels"]
-    mels = make_inputs(fields, n_utt, frames, rank)
-    batch = gomel_amd.Batch(engine, [frames * K] * n_utt)
-    seeds = [1000 + rank * n_utt + u for u in range(n_utt)]
-    batch.upload(mels, None, seeds)     # inputs resident in HBM before the clock starts
-    del mels
+    nb = min(BLOCK, n_local)
+    alloc = gomel_amd.host_alloc if pinned else (lambda shape, dtype=np.float64: np.zeros(shape, dtype=dtype))
+    mels = []
+    for u, src in enumerate(make_inputs(fields, nb, frames, first)):
+        a = alloc((frames * K, 2))
+        a[:] = src
+        mels.append(a)
+    L = engine.out_len(frames * K)
+    outs = [alloc(L) for _ in range(nb)]
+    for o in outs:
+        o[:] = 0.0                                                   # touched: what a caller's own slices are
+    blocks = [(b0, min(nb, n_local - b0)) for b0 in range(0, n_local, nb)]
+
+    def step():
+        for b0, cnt in blocks:
+            seeds = [1000 + first + b0 + u for u in range(cnt)]      # the seed of an utterance is its GLOBAL index
+            engine.from_mel_batch(mels[:cnt], None, seeds, outs[:cnt])
+
     for _ in range(warmup):
-        batch.run()
-    batch.sync()
+        step()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        batch.run()
-    batch.sync()
+        step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    tm = batch.run_timed()              # HIP events on the library's stream, outside the timed region
-    out0 = batch.download()[0]
+    last_b0, last_cnt = blocks[-1]
+    return elapsed, mels[:last_cnt], [1000 + first + last_b0 + u for u in range(last_cnt)], [np.array(o) for o in outs[:last_cnt]]
+
+
+def resident(engine, fields, n_utt, frames, first, steps):
+    """Inputs already in HBM, output left in HBM: the device-side rate, and the HIP-event timing of the dominant kernel."""
+    import gomel_amd
+    K = fields["NumMels"]
+    mels = make_inputs(fields, n_utt, frames, first)
+    batch = gomel_amd.Batch(engine, [frames * K] * n_utt)
+    batch.upload(mels, None, [1000 + first + u for u in range(n_utt)])
+    del mels
+    batch.run()
+    batch.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+    batch.sync()
+    dt = time.perf_counter() - t0
+    tm = batch.run_timed()              # HIP events on the library's stream around every launch of the dominant kernel
     batch.close()
-    return elapsed, tm, out0
-
-
-def host_buffer_rate(engine, fields, n_utt, frames, rank):
-    """The drop-in entry point as Go would call it in bulk: host fp64 in, host fp64 out (plan + H2D + run + D2H through
-    pageable buffers).  Reported next to the HBM-resident figure, never as `value`."""
-    mels = make_inputs(fields, n_utt, frames, rank)
-    seeds = [1000 + rank * n_utt + u for u in range(n_utt)]
-    outs = [np.zeros(engine.out_len(len(m))) for m in mels]     # caller-owned, already touched (what a Go caller's slices are)
-    engine.from_mel_batch(mels, None, seeds, outs)              # warm: first-use allocation and page registration costs
-    t = time.perf_counter()
-    engine.from_mel_batch(mels, None, seeds, outs)
-    return n_utt * frames / (time.perf_counter() - t)
+    return n_utt * frames * steps / dt, tm
 
 
 def config1(local_rank):
     """BASELINE configs[0]: towav geometry (cmd/towav/main.go:30-40, 2 iterations) on a PNG.  The PNG named there (the
     reference's README banner, 183x80) cannot run with NumMels = 192: the reference panics, the C ABI returns a status.  The
     same pipeline then runs on the repository's 192-row fixture, on the GPU and through the C restatement on one host core."""
-    import ctypes
     import gomel_amd
     from gomel_amd import codec, _lib
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -152,32 +220,62 @@ def config1(local_rank):
     return out
 
 
-def cpu_baseline(fields, frames, max_seconds_hint=30.0):
-    """The C restatement of the reference algorithm (oracle/gomel_oracle.c) on the host cores: one 400-frame utterance
-    per thread, same geometry and iteration count as the GPU workload."""
+def cpu_legs(fields, frames, mels, seeds, outs, mode):
+    """ONE run of the C restatement of the reference algorithm (oracle/gomel_oracle.c) serves two purposes, outside every timed
+    region: it is the reported CPU baseline (utterance-parallel host threads, the very utterances the GPU just computed) and it
+    is the checker of those GPU results (`parity`).  `mode`: all | sample | none."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gomel_oracle as go
     import oracle_c
     co = oracle_c.load()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))  # a one-GPU box gives this job a 16-CPU share whatever the affinity mask says
+    cores, how = host_cpus()
     cfg = go.MelConfig(**fields)
-    # calibrate on a few frames so the sample stays in the 10-30 s range whatever the host is
     small = go.random_logmel(4, cfg.NumMels, seed=0)
     t = time.perf_counter()
     co.from_mel(cfg, small, go.x0_splitmix(0, go.out_len(cfg, len(small))))
-    per_frame = (time.perf_counter() - t) / 4.0
-    f_s = int(max(8, min(frames, (max_seconds_hint / 2.0) / max(per_frame, 1e-6))))
-    reps = int(min(8, max(1, math.ceil(10.0 / max(f_s * per_frame, 1e-3)))))   # aim at 10-30 s of wall time on the sample
-    mels = [go.random_logmel(f_s, cfg.NumMels, seed=u) for u in range(cores * reps)]
-    x0s = [go.x0_splitmix(1000 + u, go.out_len(cfg, len(m))) for u, m in enumerate(mels)]
+    per_frame = (time.perf_counter() - t) / 4.0                      # one thread, seconds per frame (all iterations)
+    est_all = len(mels) * frames * per_frame / cores
+    if mode == "all" and est_all > 150.0:
+        mode = "sample"                                              # a small host: keep the default run within minutes
+    pick = list(range(len(mels)))
+    if mode == "sample":
+        want_n = int(max(cores, min(len(mels), 45.0 * cores / max(frames * per_frame, 1e-9))))
+        pick = sorted(set(np.linspace(0, len(mels) - 1, min(len(mels), want_n)).astype(int).tolist()))
+    L = go.out_len(cfg, len(mels[0]))
     t = time.perf_counter()
-    _, used = co.from_mel_batch(cfg, mels, x0s, threads=cores)
+    want, used = co.from_mel_batch(cfg, [np.asarray(mels[u]) for u in pick], [go.x0_splitmix(seeds[u], L) for u in pick], threads=cores)
     dt = time.perf_counter() - t
-    return {"value": len(mels) * f_s / dt, "unit": "frames/s", "cores": int(used), "kind": "port",
-            "sample": "%d utterances x %d frames x %d iters on %d threads, C restatement of mel.go:76-152, %.1f s" % (
-                len(mels), f_s, cfg.GriffinLimIterations, cores, dt),
-            "single_thread_frames_per_s": 1.0 / per_frame}
+    err = np.array([float(np.sqrt(np.mean((outs[u] - w) ** 2))) for u, w in zip(pick, want)])
+    sig = float(np.mean([np.sqrt(np.mean(w * w)) for w in want]))
+    cpu = {"value": len(pick) * frames / dt, "unit": "frames/s", "cores": int(used), "kind": "port",
+           "sample": "%d of the %d utterances of the timed batch x %d frames x %d iters, C restatement of mel.go:76-152, %d threads (%s), %.1f s" % (
+               len(pick), len(mels), frames, cfg.GriffinLimIterations, int(used), how, dt),
+           "single_thread_frames_per_s": 1.0 / per_frame, "cpu_model": cpu_model(), "go_probe": go_probe()}
+    # "CPU-strong" (BASELINE.md 3, informational): the GPU's formulation on the CPU -- real FFT + X/|X| -- NumPy / pocketfft, 1 process
+    M = go.target_magnitudes(cfg, np.exp(go.random_logmel(16, cfg.NumMels, seed=1)))
+    x0 = go.x0_splitmix(1, cfg.Resolut + 15 * cfg.Window)
+    t = time.perf_counter()
+    go.griffin_lim_rfft(go.hann(cfg.Resolut), cfg.Window, M, cfg.GriffinLimIterations, x0)
+    cpu["cpu_strong_numpy_rfft_1_process_frames_per_s"] = 16.0 / (time.perf_counter() - t)
+    parity = {"checked_utterances": len(pick), "of": len(mels), "tolerance": 1e-4, "max": float(err.max()), "p99": float(np.percentile(err, 99)),
+              "p90": float(np.percentile(err, 90)), "median": float(np.median(err)), "n_over_1e-4": int((err > 1e-4).sum()),
+              "worst_utterances": [int(pick[i]) for i in np.argsort(-err)[:3]], "signal_rms": sig,
+              "oracle": "oracle/gomel_oracle.c (fp64 restatement, parity unpinned: no Go toolchain / reference vectors)",
+              "note": "fp32 kernels vs fp64 reference arithmetic on iid-random (inconsistent) spectrograms: see DESIGN.md 'Parity in numbers'; "
+                      "gomel_set_precision(h, 64) matches to 1e-12"}
+    return cpu, parity
+
+
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher: start the N ranks as a child (torch.distributed.run) BEFORE anything touches the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -185,11 +283,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: cfg3 on one GPU, cfg5 (sharded corpus) on several")
     ap.add_argument("--utts-per-gpu", type=int, default=0)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-single", action="store_true", help="skip the single-utterance (configs[1]) side measurement")
+    ap.add_argument("--parity", default=None, choices=["all", "sample", "none"], help="oracle check of the timed batch (default: all at N=1)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (baseline + parity)")
+    ap.add_argument("--no-single", action="store_true", help="skip the side measurements (configs[1], configs[0], pageable buffers)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -215,12 +317,17 @@ def main():
         if world > 1:
             dist.barrier()
 
-    desc, fields, n_utt, frames, sr = WORKLOADS[args.workload]
-    strong = args.workload in STRONG
+    wl = args.workload or ("cfg3" if world == 1 else "cfg5")
+    desc, fields, n_utt, frames, sr = WORKLOADS[wl]
+    strong = wl in STRONG
     if strong:
-        n_utt = n_utt // world            # contiguous shard of the fixed corpus
+        first = rank * (n_utt // world)   # contiguous shard of the fixed corpus
+        n_utt = n_utt // world
+    else:
+        first = rank * n_utt
     if args.utts_per_gpu > 0:
         n_utt = args.utts_per_gpu
+        first = rank * n_utt
 
     # table blob ("mel basis"): rank 0 builds, broadcast over RCCL/xGMI, every rank creates its handle from it
     from gomel_amd import dist as gdist
@@ -228,29 +335,42 @@ def main():
     engine = gdist.create_engine_broadcast(lambda tables=None: build_engine(fields, local_rank, tables), rank, world, device=coll_dev)
     bcast_s = time.perf_counter() - t0
 
-    elapsed, tm, out0 = run_workload(engine, fields, n_utt, frames, rank, args.steps, args.warmup, barrier)
+    elapsed_local, mels_last, seeds_last, outs_last = host_to_host(engine, fields, n_utt, frames, first, args.steps, args.warmup, barrier)
+    elapsed = elapsed_local
+    per_rank = [n_utt * frames * args.steps / elapsed_local]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
-    single = None
-    if rank == 0 and world == 1 and not args.no_single and args.workload != "cfg2":
-        d2, f2, u2, fr2, sr2 = WORKLOADS["cfg2"]
-        e2 = build_engine(f2, local_rank)
-        el2, tm2, _ = run_workload(e2, f2, u2, fr2, 0, max(3, args.steps), 1, lambda: None)
-        steps2 = max(3, args.steps)
-        fps2 = u2 * fr2 * steps2 / el2
-        single = {"workload": d2, "frames_per_s": fps2, "ms_per_utterance": el2 / steps2 * 1e3,
-                  "real_time_factor": fps2 * f2["Window"] / sr2}
-        e2.close()
+    # device-side figures (outside the timed region): one BLOCK resident in HBM
+    res_fps, tm = resident(engine, fields, min(n_utt, BLOCK), frames, first, max(3, min(args.steps, 10)))
 
-    side = rank == 0 and world == 1 and not args.no_single       # side measurements and the CPU leg: N = 1 only
-    host_rate = host_buffer_rate(engine, fields, n_utt, frames, rank) if side else None
-    cfg1 = config1(local_rank) if side else None
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(fields, frames)
+    side = rank == 0 and world == 1 and not args.no_single           # side measurements: N = 1 only
+    single = pageable = cfg1 = None
+    if side:
+        if wl != "cfg2":
+            d2, f2, u2, fr2, sr2 = WORKLOADS["cfg2"]
+            e2 = build_engine(f2, local_rank)
+            fps2, tm2 = resident(e2, f2, u2, fr2, 0, 20)
+            el2, _, _, _ = host_to_host(e2, f2, u2, fr2, 0, 20, 2, lambda: None)
+            single = {"workload": d2, "resident_frames_per_s": fps2, "resident_ms_per_utterance": u2 * fr2 / fps2 * 1e3,
+                      "host_to_host_ms_per_utterance": el2 / 20 * 1e3, "real_time_factor_host_to_host": u2 * fr2 * 20 / el2 * f2["Window"] / sr2,
+                      "kernel_path": "fused" if tm2["fast_path"] else "generic"}
+            e2.close()
+        el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
+        pageable = min(n_utt, BLOCK) * frames * 3 / el_p
+        cfg1 = config1(local_rank)
+    cpu = parity = None
+    if rank == 0 and not args.no_cpu:
+        mode = args.parity or ("all" if world == 1 else "sample")
+        if mode != "none":
+            cpu, parity = cpu_legs(fields, frames, mels_last, seeds_last, outs_last, mode)
+        if world > 1:
+            cpu = None                                                # the CPU baseline is an N = 1 figure
 
     if rank == 0:
         N, hop, I = fields["Resolut"], fields["Window"], fields["GriffinLimIterations"]
@@ -260,7 +380,8 @@ def main():
         t_launch = tm["dom_ms"] / launches * 1e-3
         bytes_launch = tm["frames"] * algorithmic_bytes_per_frame_iter(N, hop)
         achieved = bytes_launch / t_launch / 1e9
-        traffic = gdist.committed_traffic(args.workload, tm["fast_path"])
+        traffic, traffic_source = committed_traffic(wl if wl != "cfg5" else "cfg3", tm["fast_path"])
+        per_frame_bytes = I * algorithmic_bytes_per_frame_iter(N, hop) + fields["NumMels"] * 16 + hop * 8
         line = {
             "metric": "Griffin-Lim frames/s (4096-pt, 60 iters)" if N == 4096 else "Griffin-Lim frames/s (%d-pt, %d iters)" % (N, I),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -268,19 +389,23 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "utterances_per_gpu": n_utt, "frames_per_utterance": frames, "resolut": N, "window_hop": hop,
                        "num_mels": fields["NumMels"], "iterations": I, "parallelism": "utterance-sharded x%d" % world,
-                       "kernel_path": "fused" if tm["fast_path"] else "generic"},
+                       "kernel_path": "fused" if tm["fast_path"] else "generic",
+                       "timed_region": "gomel_from_mel_batch host-to-host (pinned fp64 buffers, H2D + all device work + D2H), %d utterances per call" % min(n_utt, BLOCK)},
             "real_time_factor": value * hop / sr,
+            "resident_frames_per_s": res_fps,
+            "pageable_frames_per_s": pageable,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "whole_job_frac": value / world * (I * algorithmic_bytes_per_frame_iter(N, hop) + fields["NumMels"] * 16 + hop * 8) / 1e9 / HBM_PEAK_GBS},
+                         "whole_job_frac_resident": res_fps * per_frame_bytes / 1e9 / HBM_PEAK_GBS,
+                         "whole_job_frac_host_to_host": value / world * per_frame_bytes / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
+            "parity": parity,
             "single_utterance": single,
-            "host_buffers_frames_per_s": host_rate,
             "config1_towav_png_2_iters": cfg1,
+            "world_size": world, "backend": backend if world > 1 else None, "per_rank_frames_per_s": per_rank,
             "table_broadcast_s": bcast_s,
             "device_ms": {"total": tm["total_ms"], "iterations": tm["iter_ms"], "dominant_kernel": tm["dom_ms"]},
-            "output_rms": float(np.sqrt(np.mean(out0 * out0))),
         }
         print(json.dumps(line), flush=True)
     engine.close()

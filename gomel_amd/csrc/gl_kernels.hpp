@@ -438,7 +438,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
-        // this frame's magnitudes: issued now, not touched before the spectral step (a whole forward FFT of cover)
+        // this frame's magnitudes: issued now, not touched before the spectral step (a whole forward FFT of cover; fetching them a
+        // frame ahead was measured: no change on any geometry, 16 more registers)
         MagRaw mraw;
         load_mag_rows<G>(mraw, t, mag_p + (int64_t)gg * G::C);
         if constexpr (T >= 64) mraw.nq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq_all), gg));

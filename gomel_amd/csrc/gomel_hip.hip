@@ -61,7 +61,7 @@ static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
 struct DevPool {
     struct Block { void* p; size_t bytes; bool used; uint64_t stamp; };
     std::vector<Block> blocks;
-    size_t cached = 0, cap = (size_t)4 << 30;   // bytes kept while unused (GOMEL_POOL_MB; 0 = no caching)
+    size_t cached = 0, cap = (size_t)16 << 30;  // bytes kept while unused (GOMEL_POOL_MB; 0 = no caching); the device has 288 GB
     uint64_t clock = 0;
     hipError_t alloc(void** out, size_t bytes) {
         bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
@@ -310,6 +310,11 @@ struct PinRegistry {
     struct Entry { size_t bytes; int users; };
     std::mutex mu;
     std::map<uintptr_t, Entry> live;   // base -> extent, users
+    // Ranges found pinned (or device memory) by somebody else -- gomel_host_alloc / hipHostMalloc buffers a bulk caller reuses.
+    // Asking the runtime costs ~10-20 us per pointer (hipPointerGetAttributes), 5-10 ms for the 768 buffers of a 256-utterance
+    // call; the answer is remembered per allocation.  A stale entry (buffer freed, address reused by pageable memory) only
+    // means that buffer is not pinned for the call: slower copy, same result.
+    std::map<uintptr_t, size_t> foreign;   // allocation base -> size
     // returns the base of the registration that now covers [p, p+bytes) (a token for release), or 0
     uintptr_t acquire(void* p, size_t bytes) {
         const uintptr_t a = (uintptr_t)p;
@@ -321,8 +326,20 @@ struct PinRegistry {
             if (a < pr->first + pr->second.bytes) return 0;                                          // straddles its end
         }
         if (it != live.end() && it->first < a + bytes) return 0;                                      // runs into the next one
+        {
+            auto f = foreign.upper_bound(a);
+            if (f != foreign.begin()) { auto pf = std::prev(f); if (a + bytes <= pf->first + pf->second) return 0; }
+        }
         hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) return 0;  // device / pinned by the caller
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) {      // device / pinned by the caller
+            hipDeviceptr_t base = nullptr; size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && base && size) {
+                if (foreign.size() > 65536) foreign.clear();
+                foreign[(uintptr_t)base] = size;
+            }
+            (void)hipGetLastError();
+            return 0;
+        }
         (void)hipGetLastError();
         const bool ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
@@ -349,7 +366,7 @@ static PinRegistry g_pins;
 struct PinnedScope {
     std::vector<std::pair<void*, size_t>> wanted;
     std::vector<uintptr_t> held;
-    hipStream_t drain[2] = {nullptr, nullptr};
+    hipStream_t drain[2] = {nullptr, nullptr}, extra = nullptr;
     void want(const void* p, size_t bytes) {
         if (!p || bytes < (1u << 20)) return;
         void* q = const_cast<void*>(p);
@@ -361,10 +378,10 @@ struct PinnedScope {
         for (auto& w : wanted) if (uintptr_t t = g_pins.acquire(w.first, w.second)) held.push_back(t);
         wanted.clear();
     }
-    void pin(const void* p, size_t bytes, hipStream_t s0 = nullptr) { want(p, bytes); commit(s0 ? s0 : drain[0], drain[1]); }
+    void drain_too(hipStream_t s) { extra = s; }
     ~PinnedScope() {
         if (held.empty()) return;
-        for (hipStream_t s : drain) if (s) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); }
+        for (hipStream_t s : {drain[0], drain[1], extra}) if (s) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); }
         for (uintptr_t t : held) g_pins.release(t);
     }
 };
@@ -445,19 +462,36 @@ static int64_t fused_min_frames(const gomel_config& c) {
     return base * gmin / 3;
 }
 
+// Segment plan of the fused kernel.  What matters (scripts/chunk_probe.py): segments of 25-40 frames amortise the 16-row
+// prologue and the workgroup's table fill, and the NUMBER of segments should fill whole rounds of the chip: a workgroup takes
+// STREAMS segments and 2 workgroups fit a CU, so one round is 512 workgroups; 533 workgroups cost two rounds (1.75 M frames/s
+// where 512 reach 1.95 M on the same 12 800 frames).  So: pick the number of rounds r for ~28 frames per segment, aim at
+// r * 512 * STREAMS segments in total, and give each utterance its share in proportion to its frames.
 static void plan_segments(gomel_batch* b) {
     const gomel_config& c = b->h->cfg;
     const int sh = fused_shift(c), keep = 16 - sh, gmin = (keep + sh - 1) / sh;
-    int gt = (int)std::min<int64_t>(std::max<int64_t>(b->total_frames / 4096, gmin), 48);
-    if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) gt = std::min(std::max(v, gmin), kMaxSegFrames); }  // tuning knob
+    const int streams = kFusedThreads / (c.resolut / 32);                      // segments per workgroup (T = N/32 lanes per stream)
+    const int64_t per_round = (int64_t)512 * streams;
+    int64_t rounds = std::max<int64_t>(1, (b->total_frames + 14 * per_round) / (28 * per_round));
+    double target = (double)(rounds * per_round);                              // segments wanted in total
+    int forced = 0;
+    if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) forced = std::min(std::max(v, gmin), kMaxSegFrames); }  // tuning knob
     b->segs.clear();
     b->g_max = 0;
+    int64_t frames_done = 0;
+    double segs_done = 0;
     for (const UttDesc& u : b->utts) {
-        int nseg = std::max(1, (u.frames + gt / 2) / gt);
+        int nseg;
+        if (forced) nseg = std::max(1, (u.frames + forced / 2) / forced);
+        else {   // this utterance's share of the target, carried over utterances so that the total lands on it
+            const double want = target * (double)(frames_done + u.frames) / (double)b->total_frames - segs_done;
+            nseg = std::max(1, (int)std::llround(want));
+        }
         while (nseg > 1 && u.frames / nseg < gmin) nseg--;
         // hard cap kMaxSegFrames frames per segment (k_gl_fused keeps one Nyquist magnitude per lane); it wins over gmin, which
         // only matters for has_next segments of very short utterances and gmin <= 15 < 64 / 2 always leaves room
         nseg = std::max(nseg, (u.frames + kMaxSegFrames - 1) / kMaxSegFrames);
+        frames_done += u.frames; segs_done += nseg;
         const int base = u.frames / nseg, rem = u.frames % nseg;
         int f0 = 0;
         for (int s = 0; s < nseg; s++) {
@@ -988,9 +1022,10 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
         if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
         total_frames += (int64_t)(n_pairs[u] / (size_t)K);
     }
-    // chunk plan: at least ~12k frames per chunk (enough to fill the chip several times over), at most 8 chunks
+    // chunk plan: at least ~12k frames per chunk (half a round of the chip: the kernels still run at 2.3 of the 2.6 M frames/s
+    // of a big batch, scripts/chunk_probe.py, and more chunks expose less of the first upload / last download), at most 16
     const int64_t kMinChunkFrames = 12288;
-    int n_chunks = (int)std::min<int64_t>(8, std::max<int64_t>(1, total_frames / kMinChunkFrames));
+    int n_chunks = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
     if (const char* e = getenv("GOMEL_CHUNKS")) { int v = atoi(e); if (v > 0) n_chunks = std::min(v, 64); }   // tuning knob
     n_chunks = (int)std::min<size_t>((size_t)n_chunks, n_utt);
     std::vector<size_t> bounds(1, 0);
@@ -1012,24 +1047,31 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
     } chunk_list;
     std::vector<gomel_batch*>& chunks = chunk_list.v;
     chunks.assign((size_t)n_chunks, nullptr);
-    int rc = GOMEL_OK;
-    for (int c = 0; c < n_chunks && !rc; c++) rc = batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c]);
-    if (!rc) {
-        std::lock_guard<std::mutex> lk(h->mu);
-        DeviceGuard dg(h->device);
-        if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
+    // At most three chunks hold device buffers at a time (uploading c+1, computing c, downloading c-1): chunk c-2's batch is
+    // destroyed -- its buffers go back to the handle's pool -- before chunk c+1's is created, so a call of any size cycles
+    // through three sets of buffers instead of allocating one per chunk.
+    auto create = [&](int c) { return batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c]); };
+    int rc = create(0);
+    std::vector<hipEvent_t> done((size_t)n_chunks, nullptr), up((size_t)n_chunks, nullptr), down((size_t)n_chunks, nullptr);
+    std::vector<std::vector<uint64_t>> gseeds((size_t)n_chunks);   // default seed = GLOBAL utterance index, whatever the chunking
+    {
         PinnedScope pins;
-        std::vector<hipEvent_t> done((size_t)n_chunks, nullptr), up((size_t)n_chunks, nullptr);
-        for (size_t u = 0; u < n_utt && !rc; u++) {
-            pins.want(mel[u], n_pairs[u] * 2 * esz);
-            pins.want(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * esz);
-            if (x0 && x0[u]) pins.want(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * esz);
+        if (!rc) {
+            std::lock_guard<std::mutex> lk(h->mu);
+            DeviceGuard dg(h->device);
+            if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
+            for (size_t u = 0; u < n_utt && !rc; u++) {
+                pins.want(mel[u], n_pairs[u] * 2 * esz);
+                pins.want(out[u], gomel_out_len(&h->cfg, n_pairs[u]) * esz);
+                if (x0 && x0[u]) pins.want(x0[u], gomel_out_len(&h->cfg, n_pairs[u]) * esz);
+            }
+            pins.commit(h->stream, h->copy_stream);
+            pins.drain_too(h->up_stream);
+            for (int c = 0; c < n_chunks && !rc; c++)
+                if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&up[c], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&down[c], hipEventDisableTiming) != hipSuccess) rc = GOMEL_ERR_HIP;
         }
-        pins.commit(h->stream, h->copy_stream);
-        for (int c = 0; c < n_chunks && !rc; c++)
-            if (hipEventCreateWithFlags(&done[c], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&up[c], hipEventDisableTiming) != hipSuccess) rc = GOMEL_ERR_HIP;
-        std::vector<std::vector<uint64_t>> gseeds((size_t)n_chunks);   // default seed = GLOBAL utterance index, whatever the chunking
-        auto upload = [&](int c) {
+        auto upload = [&](int c) {   // caller holds h->mu
             gomel_batch* b = chunks[c];
             const size_t u0 = bounds[c];
             if (!seeds) { gseeds[c].resize(b->n_utt); for (size_t u = 0; u < b->n_utt; u++) gseeds[c][u] = (uint64_t)(u0 + u); }
@@ -1037,8 +1079,17 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
             if (!r && hipEventRecord(up[c], h->up_stream) != hipSuccess) r = GOMEL_ERR_HIP;
             return r;
         };
-        if (!rc) rc = upload(0);
+        if (!rc) { std::lock_guard<std::mutex> lk(h->mu); DeviceGuard dg(h->device); rc = upload(0); }
         for (int c = 0; c < n_chunks && !rc; c++) {
+            if (c >= 2) {   // chunk c-2 has computed; once its waveforms are down its buffers serve chunk c+1
+                DeviceGuard dg(h->device);
+                if (hipEventSynchronize(down[c - 2]) != hipSuccess) { rc = GOMEL_ERR_HIP; break; }
+                gomel_batch_destroy(chunks[c - 2]); chunks[c - 2] = nullptr;
+            }
+            if (c + 1 < n_chunks) rc = create(c + 1);                                 // (takes and drops h->mu itself)
+            if (rc) break;
+            std::lock_guard<std::mutex> lk(h->mu);
+            DeviceGuard dg(h->device);
             gomel_batch* b = chunks[c];
             const size_t u0 = bounds[c];
             if (c + 1 < n_chunks) rc = upload(c + 1);                                   // queued before this chunk's kernels: runs beside them
@@ -1048,12 +1099,17 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
             for (size_t u = 0; u < b->n_utt && !rc; u++)
                 if (hipMemcpyAsync(out[u0 + u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess)
                     rc = GOMEL_ERR_HIP;
+            if (!rc && hipEventRecord(down[c], h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
         }
-        if (hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
-        if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
-        for (hipEvent_t e : done) if (e) hipEventDestroy(e);
-        for (hipEvent_t e : up) if (e) hipEventDestroy(e);
-    }
+        {
+            DeviceGuard dg(h->device);
+            if (hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
+            if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
+            for (hipEvent_t e : done) if (e) hipEventDestroy(e);
+            for (hipEvent_t e : up) if (e) hipEventDestroy(e);
+            for (hipEvent_t e : down) if (e) hipEventDestroy(e);
+        }
+    }   // pins dropped here, after every stream has drained
     return rc;
 }
 

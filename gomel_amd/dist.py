@@ -3,9 +3,6 @@ between FromMel calls).  One process per GPU; contiguous utterance shards balanc
 collective.  The only collective is the one-off broadcast of the table blob ("mel basis": Hann window + undomel/domel
 tables) from rank 0 -- over RCCL/xGMI with the "nccl" backend, over gloo in the CPU tests.
 """
-import json
-import os
-
 import numpy as np
 
 
@@ -73,16 +70,3 @@ def from_mel_sharded(compute, mels, x0s=None, seeds=None, rank=0, world=1, gathe
     parts = [None] * world
     dist.all_gather_object(parts, local)
     return [w for p in parts for w in p]
-
-
-def committed_traffic(workload, fast_path):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json),
-    or None when no measurement matches this workload / kernel path."""
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
-    try:
-        with open(p) as f:
-            d = json.load(f)
-        e = d.get("%s:%s" % (workload, "fused" if fast_path else "generic"))
-        return None if e is None else e.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None

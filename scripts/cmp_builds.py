@@ -5,10 +5,21 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import importlib
 
+
+def lenient(_lib, path):
+    """Older builds of the library lack the newest entry points: drop what a build does not export from the symbol table."""
+    import ctypes
+    _lib._share_hip_runtime()
+    l = ctypes.CDLL(path)
+    _lib.SYMBOLS = {k: v for k, v in _lib.SYMBOLS.items() if hasattr(l, k)}
+
 def run(libpath, geom, U, F, I, reps):
     from gomel_amd import _lib
     _lib._lib = None
     _lib.LIB_PATH = os.path.abspath(libpath)
+    if not hasattr(_lib, "_ALL_SYMBOLS"): _lib._ALL_SYMBOLS = dict(_lib.SYMBOLS)
+    _lib.SYMBOLS = dict(_lib._ALL_SYMBOLS)
+    lenient(_lib, _lib.LIB_PATH)
     import gomel_amd
     G = {"T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096), "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),
          "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048)}[geom]

@@ -437,6 +437,9 @@ template <class G, class V> GL_DEV void lane0_permute(V (&v)[16], bool is0) {
 }
 template <class G, class V> GL_DEV void lane0_unpermute(V (&v)[16], bool is0, V dc) {
     if (is0) {
+        // one lane in 2 T needs this: keep it a real branch (waves without a lane 0 skip it, the others run it with one lane
+        // enabled) instead of 28 full-width v_cndmask per frame -- the empty asm statement stops the if-conversion
+        asm volatile("; lane 0 only" ::: );
         V pa[8], pb[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { pa[i] = v[i]; pb[i] = v[8 + i]; }

@@ -406,7 +406,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #endif
     v2f xin[16], acc[KEEP];
     const v2f* wl = win_l + t;  // window pair of row j: wl[T*j]
-    const v2f wt = tb.wn[t];
+    // the eight W_N^k of this lane's bin pairs: frame-independent, computed once per segment from one table value and kept
+    // (16 registers; rebuilding them every frame was 16 packed multiplies per frame)
+    v2f wn[8];
+    make_wn<G>(wn, t, tb.wn[t]);
     // Tail terms are loaded unconditionally (clamped row, times a 0/1 flag) so that all loads of a frame go out together
     // instead of one branch + vmcnt(0) each; tail buffers are zero-filled at allocation, unused tails stay zero.
 #pragma unroll
@@ -468,10 +471,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         // rows past the owned range (the last frames of a segment with a successor) also take the successor's head from the tail
         // buffer: rare, so behind a (wave-uniform for T >= 64) branch instead of SH more loads in every frame
         const bool any_next = more && d.has_next && row0 + SH - 1 >= rows_owned;
-        v2f tl[SH];
+        v2f tl[SH];          // (read only under any_next: no zero-fill of 3 SH registers in every frame)
         float fl[SH];
-#pragma unroll
-        for (int jj = 0; jj < SH; jj++) { tl[jj] = v2f{0.f, 0.f}; fl[jj] = 0.f; }
         if (any_next) {
 #pragma unroll
             for (int jj = 0; jj < SH; jj++) {
@@ -485,8 +486,6 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         {
             MagRegs mr;
             finish_mags(mr, mraw, t == 0);
-            v2f wn[8];
-            make_wn<G>(wn, t, wt);
             spectral_apply<G>(v, t, mr, wn);
         }
         st.mark(7);

@@ -1,11 +1,16 @@
 // Package mel: drop-in replacement for the hot path of github.com/neurlang/gomel/mel, calling libgomel_hip.so
 // (include/gomel_hip.h) through cgo.  Same exported names and field set as the reference's `type Mel`
-// (mel/mel.go:10-27); ToMel / FromMel run on the GPU, everything else (PNG/WAV codec, pad, ToWavPng's glue) stays the
-// reference's own Go code and is not repeated here.
+// (mel/mel.go:10-27); ToMel / FromMel / ISTFT run on the GPU, everything else (PNG/WAV codec, pad, ToWavPng's glue) stays
+// the reference's own Go code and is not repeated here.
+//
+// `Mel` stays what it is in the reference: a plain value of exported fields that callers may copy (`m2 := *m`), compare and
+// drop without ceremony.  Device handles therefore do NOT live in the struct: they sit in a small package-level cache keyed by
+// the configuration (at most maxEngines live handles, least recently used evicted once idle), so there is no mutex to copy
+// (go vet copylocks), no double free between copies and nothing to Close.  ReleaseEngines() frees the cache explicitly.
 //
 // NOT COMPILED IN THIS REPOSITORY'S PIPELINE: there is no Go toolchain in the build image (SURVEY Appendix E).  The file
-// is the binding a maintainer adds next to mel/mel.go, replacing the bodies of ToMel and FromMel; it is kept small and
-// mechanical on purpose.  Build: CGO_CFLAGS=-I<repo>/include CGO_LDFLAGS="-L<repo>/gomel_amd -lgomel_hip".
+// is the binding a maintainer adds next to mel/mel.go, replacing the bodies of ToMel, FromMel and ISTFT (INTEGRATION.md).
+// Build: CGO_CFLAGS=-I<repo>/include CGO_LDFLAGS="-L<repo>/gomel_amd -lgomel_hip -Wl,-rpath,<repo>/gomel_amd".
 package mel
 
 /*
@@ -20,6 +25,7 @@ import (
 	"math"
 	"math/cmplx"
 	"math/rand"
+	"runtime"
 	"sync"
 	"unsafe"
 
@@ -40,10 +46,6 @@ type Mel struct {
 	GriffinLimIterations int
 	VolumeBoost          float64
 	SampleRate           int
-
-	mu     sync.Mutex
-	handle *C.gomel_handle
-	key    C.gomel_config
 }
 
 // NewMel creates a new Mel instance with default values (mel/mel.go:30-41).
@@ -60,46 +62,110 @@ func statusErr(rc C.int) error {
 	return errors.New("gomel_hip: " + C.GoString(C.gomel_strerror(rc)))
 }
 
-// engine (re)creates the device handle when the exported fields changed since the last call.
-func (m *Mel) engine() (*C.gomel_handle, error) {
+// ---- handle cache -------------------------------------------------------------------------------------------------------
+
+type engineKey struct {
+	numMels, window, resolut, iters int32
+	fmin, fmax, tuneMul, tuneAdd   float64
+}
+
+type engine struct {
+	h    *C.gomel_handle
+	cfg  C.gomel_config
+	refs int    // calls in flight (the C library serialises them on its own mutex)
+	used uint64 // LRU stamp
+}
+
+const maxEngines = 8
+
+var (
+	enginesMu sync.Mutex
+	engines   = map[engineKey]*engine{}
+	useClock  uint64
+)
+
+func (m *Mel) key() engineKey {
+	return engineKey{int32(m.NumMels), int32(m.Window), int32(m.Resolut), int32(m.GriffinLimIterations), m.MelFmin, m.MelFmax, m.TuneMul, m.TuneAdd}
+}
+
+// acquire returns the handle for m's current field values, creating it on first use; release() must follow.
+func (m *Mel) acquire() (*engine, error) {
+	k := m.key()
+	enginesMu.Lock()
+	defer enginesMu.Unlock()
+	useClock++
+	if e, ok := engines[k]; ok {
+		e.refs++
+		e.used = useClock
+		return e, nil
+	}
 	var c C.gomel_config
 	C.gomel_default_config(&c)
 	c.num_mels, c.window, c.resolut = C.int32_t(m.NumMels), C.int32_t(m.Window), C.int32_t(m.Resolut)
 	c.griffin_lim_iterations = C.int32_t(m.GriffinLimIterations)
 	c.mel_fmin, c.mel_fmax, c.tune_mul, c.tune_add = C.double(m.MelFmin), C.double(m.MelFmax), C.double(m.TuneMul), C.double(m.TuneAdd)
-	if m.handle != nil && c == m.key {
-		return m.handle, nil
-	}
-	if m.handle != nil {
-		C.gomel_destroy(m.handle)
-		m.handle = nil
-	}
-	if rc := C.gomel_create(&c, &m.handle); rc != C.GOMEL_OK {
+	e := &engine{cfg: c, refs: 1, used: useClock}
+	if rc := C.gomel_create(&c, &e.h); rc != C.GOMEL_OK {
 		return nil, statusErr(rc)
 	}
-	m.key = c
-	return m.handle, nil
+	engines[k] = e
+	for len(engines) > maxEngines { // evict idle handles, least recently used first
+		var victimK engineKey
+		var victim *engine
+		for kk, ee := range engines {
+			if ee.refs == 0 && (victim == nil || ee.used < victim.used) {
+				victimK, victim = kk, ee
+			}
+		}
+		if victim == nil {
+			break
+		}
+		C.gomel_destroy(victim.h)
+		delete(engines, victimK)
+	}
+	return e, nil
 }
+
+func (e *engine) release() {
+	enginesMu.Lock()
+	e.refs--
+	enginesMu.Unlock()
+}
+
+// ReleaseEngines destroys every idle device handle of the cache (no counterpart in the reference, which holds no resources).
+func ReleaseEngines() {
+	enginesMu.Lock()
+	defer enginesMu.Unlock()
+	for k, e := range engines {
+		if e.refs == 0 {
+			C.gomel_destroy(e.h)
+			delete(engines, k)
+		}
+	}
+}
+
+// ---- the hot path -------------------------------------------------------------------------------------------------------
 
 // ToMel generates a mel spectrogram from a wave buffer (mel/mel.go:46-74).
 func (m *Mel) ToMel(buf []float64) ([][2]float64, error) {
-	m.mu.Lock()
-	defer m.mu.Unlock()
-	h, err := m.engine()
-	if err != nil {
-		return nil, err
-	}
 	if len(buf) == 0 {
 		return nil, statusErr(C.GOMEL_ERR_EMPTY)
 	}
-	n := int(C.gomel_to_mel_pairs(&m.key, C.size_t(len(buf))))
+	e, err := m.acquire()
+	if err != nil {
+		return nil, err
+	}
+	defer e.release()
+	n := int(C.gomel_to_mel_pairs(&e.cfg, C.size_t(len(buf))))
 	out := make([][2]float64, n)
 	if n == 0 {
 		return out, statusErr(C.GOMEL_ERR_TOO_SHORT)
 	}
 	var got C.size_t
-	rc := C.gomel_to_mel(h, (*C.double)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)),
+	rc := C.gomel_to_mel(e.h, (*C.double)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)),
 		(*C.double)(unsafe.Pointer(&out[0][0])), C.size_t(n), &got)
+	runtime.KeepAlive(buf)
+	runtime.KeepAlive(out)
 	return out[:int(got)], statusErr(rc)
 }
 
@@ -107,16 +173,15 @@ func (m *Mel) ToMel(buf []float64) ([][2]float64, error) {
 // block of 2*len float64, passed without copying; the initial signal comes from math/rand's global source exactly as
 // in the reference (mel/mel.go:81-83), so seeding behaves as before.
 func (m *Mel) FromMel(ospectrum [][2]float64) ([]float64, error) {
-	m.mu.Lock()
-	defer m.mu.Unlock()
-	h, err := m.engine()
-	if err != nil {
-		return nil, err
-	}
 	if len(ospectrum) == 0 {
 		return nil, statusErr(C.GOMEL_ERR_EMPTY) // the reference panics here (mel/mel.go:78)
 	}
-	L := int(C.gomel_out_len(&m.key, C.size_t(len(ospectrum))))
+	e, err := m.acquire()
+	if err != nil {
+		return nil, err
+	}
+	defer e.release()
+	L := int(C.gomel_out_len(&e.cfg, C.size_t(len(ospectrum))))
 	if L == 0 {
 		return nil, statusErr(C.GOMEL_ERR_BAD_LENGTH) // the reference panics here (mel/impl.go:366)
 	}
@@ -126,8 +191,11 @@ func (m *Mel) FromMel(ospectrum [][2]float64) ([]float64, error) {
 	}
 	out := make([]float64, L)
 	var got C.size_t
-	rc := C.gomel_from_mel(h, (*C.double)(unsafe.Pointer(&ospectrum[0][0])), C.size_t(len(ospectrum)),
+	rc := C.gomel_from_mel(e.h, (*C.double)(unsafe.Pointer(&ospectrum[0][0])), C.size_t(len(ospectrum)),
 		(*C.double)(unsafe.Pointer(&x0[0])), 0, (*C.double)(unsafe.Pointer(&out[0])), C.size_t(L), &got)
+	runtime.KeepAlive(ospectrum)
+	runtime.KeepAlive(x0)
+	runtime.KeepAlive(out)
 	// side effect of spectral_denormalize on the caller's slice (mel/mel.go:143, mel/impl.go:421-427)
 	for i := range ospectrum {
 		ospectrum[i][0] = math.Exp(ospectrum[i][0])
@@ -138,8 +206,8 @@ func (m *Mel) FromMel(ospectrum [][2]float64) ([]float64, error) {
 
 // ISTFT is the Griffin-Lim loop itself (mel/mel.go:76-139).  Of `spectrogram` the reference reads only the magnitudes of
 // bins 0..frameLen/2 (phases are re-estimated, the upper half is conjugate-filled), so those are what crosses the boundary;
-// s.Window is injected as the analysis/synthesis window.  The reference also leaves its last phase estimate in the caller's
-// spectrogram; this shim does not.
+// s.Window is injected as the analysis/synthesis window.  As in the reference (mel/mel.go:98-108) the caller's spectrogram
+// holds the last iteration's phase estimate afterwards (gomel_istft_spec returns bins 0..frameLen/2, the rest is mirrored here).
 func ISTFT(s *stft.STFT, spectrogram [][]complex128, numIterations int) []float64 {
 	numFrames, frameLen := len(spectrogram), len(spectrogram[0]) // panics on an empty spectrogram, as the reference does
 	var c C.gomel_config
@@ -166,20 +234,84 @@ func ISTFT(s *stft.STFT, spectrogram [][]complex128, numIterations int) []float6
 		x0[i] = rand.Float64()
 	}
 	out := make([]float64, L)
+	spec := make([]float64, numFrames*half*2)
 	var got C.size_t
-	if rc := C.gomel_istft(h, (*C.double)(unsafe.Pointer(&mags[0])), C.size_t(numFrames), C.int32_t(numIterations),
-		(*C.double)(unsafe.Pointer(&x0[0])), 0, (*C.double)(unsafe.Pointer(&out[0])), C.size_t(L), &got); rc != C.GOMEL_OK {
+	rc := C.gomel_istft_spec(h, (*C.double)(unsafe.Pointer(&mags[0])), C.size_t(numFrames), C.int32_t(numIterations),
+		(*C.double)(unsafe.Pointer(&x0[0])), 0, (*C.double)(unsafe.Pointer(&out[0])), C.size_t(L), &got,
+		(*C.double)(unsafe.Pointer(&spec[0])))
+	runtime.KeepAlive(mags)
+	runtime.KeepAlive(x0)
+	runtime.KeepAlive(out)
+	runtime.KeepAlive(spec)
+	if rc != C.GOMEL_OK {
 		panic(statusErr(rc))
+	}
+	if numIterations > 0 { // the reference's loop body is what writes the spectrogram
+		for i := range spectrogram {
+			for j := 0; j < half; j++ {
+				spectrogram[i][j] = complex(spec[(i*half+j)*2], spec[(i*half+j)*2+1])
+			}
+			for j := 1; j < frameLen/2; j++ {
+				spectrogram[i][frameLen-j] = cmplx.Conj(spectrogram[i][j]) // mel/mel.go:105-108
+			}
+		}
 	}
 	return out[:int(got)]
 }
 
-// Close releases the device handle (no counterpart in the reference, which holds no resources).
-func (m *Mel) Close() {
-	m.mu.Lock()
-	defer m.mu.Unlock()
-	if m.handle != nil {
-		C.gomel_destroy(m.handle)
-		m.handle = nil
+// FromMelBatch runs many independent FromMel calls in one go (no counterpart in the reference; the throughput mode).  With
+// several handles -- one per GPU, see INTEGRATION.md -- C.gomel_from_mel_batch_multi shards the utterances over the devices.
+func (m *Mel) FromMelBatch(spectra [][][2]float64) ([][]float64, error) {
+	n := len(spectra)
+	if n == 0 {
+		return nil, nil
 	}
+	e, err := m.acquire()
+	if err != nil {
+		return nil, err
+	}
+	defer e.release()
+	// pointer arrays handed to C must not be Go memory holding Go pointers: build them in C memory, pin the slices
+	ptrBytes := C.size_t(unsafe.Sizeof(uintptr(0)))
+	mels := (*[1 << 28]*C.double)(C.malloc(C.size_t(n) * ptrBytes))
+	x0s := (*[1 << 28]*C.double)(C.malloc(C.size_t(n) * ptrBytes))
+	outs := (*[1 << 28]*C.double)(C.malloc(C.size_t(n) * ptrBytes))
+	lens := (*[1 << 28]C.size_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(C.size_t(0)))))
+	defer C.free(unsafe.Pointer(mels))
+	defer C.free(unsafe.Pointer(x0s))
+	defer C.free(unsafe.Pointer(outs))
+	defer C.free(unsafe.Pointer(lens))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	res := make([][]float64, n)
+	init := make([][]float64, n)
+	for u, sp := range spectra {
+		if len(sp) == 0 {
+			return nil, statusErr(C.GOMEL_ERR_EMPTY)
+		}
+		L := int(C.gomel_out_len(&e.cfg, C.size_t(len(sp))))
+		if L == 0 {
+			return nil, statusErr(C.GOMEL_ERR_BAD_LENGTH)
+		}
+		res[u] = make([]float64, L)
+		init[u] = make([]float64, L)
+		for i := range init[u] {
+			init[u][i] = rand.Float64() // the stream the reference would have drawn, utterance after utterance
+		}
+		pin.Pin(&sp[0][0])
+		pin.Pin(&res[u][0])
+		pin.Pin(&init[u][0])
+		mels[u] = (*C.double)(unsafe.Pointer(&sp[0][0]))
+		x0s[u] = (*C.double)(unsafe.Pointer(&init[u][0]))
+		outs[u] = (*C.double)(unsafe.Pointer(&res[u][0]))
+		lens[u] = C.size_t(len(sp))
+	}
+	rc := C.gomel_from_mel_batch(e.h, C.size_t(n), &mels[0], &lens[0], &x0s[0], nil, &outs[0], nil)
+	for _, sp := range spectra {
+		for i := range sp {
+			sp[i][0] = math.Exp(sp[i][0])
+			sp[i][1] = math.Exp(sp[i][1])
+		}
+	}
+	return res, statusErr(rc)
 }

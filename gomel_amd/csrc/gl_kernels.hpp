@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "gl_fft.hpp"
+#include "gl_any.hpp"
 
 using namespace glfft;
 
@@ -25,6 +26,7 @@ struct BinRow {  // one linear bin of undomel (or one mel band of domel): data-i
 };
 
 struct DevTables {
+    glany::AnyTables any;  // generic-length path (gl_any.hpp); any.M == 0 when the register cores cover Resolut
     const float* window;   // [N]
     const v2f* tw1;        // fp32 twiddles (Griffin-Lim)
     const v2f* tw2;
@@ -47,6 +49,12 @@ struct DevTables {
         default:   { constexpr int NN = 256;  __VA_ARGS__; } break; \
     }
 static inline bool gomel_supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
+// what gl_any.hpp covers besides: even lengths that are a power of two up to 8192, or anything up to 4096 (Bluestein, M <= 8192)
+static inline bool gomel_generic_n(int n) {
+    if (n < 4 || (n & 1) || gomel_supported_n(n)) return false;
+    const bool pow2 = (n & (n - 1)) == 0;
+    return pow2 ? n <= 8192 : n <= 4096;
+}
 
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
     if (r.mode == 0) return e[r.lo];
@@ -158,6 +166,31 @@ template <class MagT>
 static void launch_mag_direct(int N, int64_t frames, hipStream_t s, const double* in, MagT* mag, MagT* nyq) {
     const double inv_n = 1.0 / (double)N;
     GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_mag_direct<NN, MagT>), dim3((unsigned)frames), dim3(256), 0, s, in, mag, nyq, inv_n));
+}
+
+// The same two kernels for the generic-length path: natural bin order, fp64, NOT divided by N (gl_any.hpp keeps fft.IFFT's 1/N explicit).
+template <class InT> GL_DEV double apply_row_exp(const BinRow r, const InT* __restrict__ m, int c) {   // apply_row on exp(channel c)
+    if (r.mode == 0) return exp((double)m[2 * r.lo + c]);
+    if (r.mode == 1) return exp((double)m[2 * r.lo + c]) * (1 - r.modlo) + exp((double)m[2 * r.hi + c]) * r.modlo;
+    double tot = 0;
+    for (int k = r.lo; k < r.hi; k++) tot += exp((double)m[2 * k + c]);
+    return tot / r.div;
+}
+__global__ __launch_bounds__(256) void k_mel_to_mag_nat(const double* __restrict__ mel, const BinRow* __restrict__ undo, double* __restrict__ mag,
+                                                        double* __restrict__ nyq, int K, int H, double tune_add, double tune_mul) {
+    const int64_t f = blockIdx.x;
+    const double* m = mel + f * (int64_t)K * 2;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const BinRow r = undo[k];
+        mag[f * H + k] = fabs((apply_row_exp(r, m, 0) - tune_add) / tune_mul);                      // mel/impl.go:396-397, channel 0 -> bin k
+        if (k == H - 1) nyq[f] = fabs((apply_row_exp(r, m, 1) - tune_add) / tune_mul);              // channel 1's last bin lands on bin N/2
+    }
+}
+__global__ __launch_bounds__(256) void k_mag_direct_nat(const double* __restrict__ in, double* __restrict__ mag, double* __restrict__ nyq, int H) {
+    const int64_t f = blockIdx.x;
+    const double* m = in + f * (H + 1);
+    for (int k = threadIdx.x; k < H; k += blockDim.x) mag[f * H + k] = fabs(m[k]);
+    if (threadIdx.x == 0) nyq[f] = fabs(m[H]);
 }
 
 // =============================================================================================== K3: initial signal

@@ -108,6 +108,7 @@ struct gomel_handle {
     int path_mode = 0;
     int precision = 32;           // 32: fp32 kernels (default); 64: fp64 generic kernels ("precise" mode)
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
+    bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
     std::vector<double> window;   // [N]
     std::vector<BinRow> undo;     // [N/2]
     std::vector<BinRow> dom;      // [K]
@@ -189,7 +190,7 @@ static int validate_config(const gomel_config* c) {
     if (!c) return GOMEL_ERR_NULL;
     if (c->num_mels <= 0 || c->num_mels > kMaxMels || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
     if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
-    if (!gomel_supported_n(c->resolut)) return GOMEL_ERR_UNSUPPORTED_N;
+    if (!gomel_supported_n(c->resolut) && !gomel_generic_n(c->resolut)) return GOMEL_ERR_UNSUPPORTED_N;
     return GOMEL_OK;
 }
 
@@ -213,7 +214,60 @@ template <class V> static void fill_twiddles(int N, int R1, int R2, std::vector<
     }
 }
 
+// Tables of the generic-length path: window (fp64 + fp32), mel rows, radix-2 twiddles of the M-point transform and, when N is
+// not a power of two, Bluestein's chirp and the transform of its filter (fp64 on the host, in the order fft_dif leaves its output).
+static int upload_tables_generic(gomel_handle* h) {
+    const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
+    const bool pow2 = (N & (N - 1)) == 0;
+    int M = 1, logM = 0;
+    while (M < (pow2 ? N : 2 * N - 1)) { M <<= 1; logM++; }
+    std::vector<v2d> tw((size_t)M / 2), chirp(pow2 ? 0 : (size_t)N), bhat(pow2 ? 0 : (size_t)M);
+    for (int j = 0; j < M / 2; j++) { const double a = -2.0 * M_PI * (double)j / (double)M; tw[j] = v2d{std::cos(a), std::sin(a)}; }
+    if (!pow2) {
+        auto w = [&](int64_t n) { const double a = -M_PI * (double)((n * n) % (2 * (int64_t)N)) / (double)N; return v2d{std::cos(a), std::sin(a)}; };   // e^{-i pi n^2 / N}
+        for (int n = 0; n < N; n++) chirp[n] = w(n);
+        std::vector<v2d> b((size_t)M, v2d{0.0, 0.0});
+        for (int n = 0; n < N; n++) { const v2d c = w(n); b[n] = v2d{c.x, -c.y}; if (n) b[M - n] = b[n]; }
+        // host FFT_M of b, decimation in frequency (the device's fft_dif): the result is already in its bit-reversed order
+        for (int s = 0; s < logM; s++) {
+            const int half = M >> (s + 1);
+            for (int idx = 0; idx < M / 2; idx++) {
+                const int grp = idx >> (logM - 1 - s), pos = idx & (half - 1), i0 = (grp << (logM - s)) + pos, i1 = i0 + half;
+                const v2d a = b[i0], c = b[i1], t = tw[(size_t)pos << s], d = v2d{a.x - c.x, a.y - c.y};
+                b[i0] = v2d{a.x + c.x, a.y + c.y};
+                b[i1] = v2d{d.x * t.x - d.y * t.y, d.x * t.y + d.y * t.x};
+            }
+        }
+        bhat = b;
+    }
+    std::vector<float> wf(N);
+    for (int i = 0; i < N; i++) wf[i] = (float)h->window[i];
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_win = carve((size_t)N * 4), o_wind = carve((size_t)N * 8), o_undo = carve((size_t)C * sizeof(BinRow)), o_dom = carve((size_t)K * sizeof(BinRow)),
+                 o_tw = carve(tw.size() * 16), o_ch = carve(chirp.size() * 16 + 16), o_bh = carve(bhat.size() * 16 + 16);
+    std::vector<char> host(off, 0);
+    memcpy(&host[o_win], wf.data(), (size_t)N * 4); memcpy(&host[o_wind], h->window.data(), (size_t)N * 8);
+    memcpy(&host[o_undo], h->undo.data(), (size_t)C * sizeof(BinRow)); memcpy(&host[o_dom], h->dom.data(), (size_t)K * sizeof(BinRow));
+    memcpy(&host[o_tw], tw.data(), tw.size() * 16);
+    if (!pow2) { memcpy(&host[o_ch], chirp.data(), chirp.size() * 16); memcpy(&host[o_bh], bhat.data(), bhat.size() * 16); }
+    if (!h->d_blob) HIPCHK(hipMalloc(&h->d_blob, off));
+    HIPCHK(hipMemcpy(h->d_blob, host.data(), off, hipMemcpyHostToDevice));
+    char* d = (char*)h->d_blob;
+    h->dt = DevTables{};
+    h->dt.window = (const float*)(d + o_win); h->dt.windowd = (const double*)(d + o_wind);
+    h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
+    h->dt.any.tw = (const v2d*)(d + o_tw); h->dt.any.chirp = (const v2d*)(d + o_ch); h->dt.any.bhat = (const v2d*)(d + o_bh);
+    h->dt.any.M = M; h->dt.any.logM = logM; h->dt.any.bluestein = pow2 ? 0 : 1;
+    if ((size_t)M * 16 > 64 * 1024) {   // the frame lives in LDS: up to 128 KiB of the CU's 160
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
+    }
+    return GOMEL_OK;
+}
+
 static int upload_tables(gomel_handle* h) {
+    if (h->generic) return upload_tables_generic(h);
     const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
     int R1 = 0, R2 = 0;
     GOMEL_DISPATCH_N(N, R1 = Geo<NN>::R1; R2 = Geo<NN>::R2);
@@ -257,6 +311,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     gomel_handle* h = new (std::nothrow) gomel_handle();
     if (!h) return GOMEL_ERR_NO_MEMORY;
     h->cfg = *cfg;
+    h->generic = !gomel_supported_n(cfg->resolut);
     if (const char* e = getenv("GOMEL_POOL_MB")) h->pool.cap = (size_t)std::max(0L, atol(e)) << 20;
     if (cfg->device >= 0) {
         if (cfg->device >= ndev) { delete h; return GOMEL_ERR_NO_DEVICE; }
@@ -443,6 +498,7 @@ struct BatchGuard {   // frees a half-built batch on every early exit, exception
 
 // The fused kernel needs hop = SH * (N/16) with SH in the instantiated set.
 static int fused_shift(const gomel_config& c) {
+    if (!gomel_supported_n(c.resolut)) return 0;          // generic-length path: gl_any.hpp kernels only
     const int row = c.resolut / 16;
     if (c.window % row) return 0;
     const int sh = c.window / row;
@@ -557,14 +613,22 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         if (tm) { HIPCHK(hipEventRecord(b->ev[1], s)); HIPCHK(hipEventRecord(b->ev[2], s)); }
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
-            if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
+            if (h->generic) {
+                if (b->direct) hipLaunchKernelGGL(k_mag_direct_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, b->d_magd, b->d_nyqd, N / 2);
+                else hipLaunchKernelGGL(k_mel_to_mag_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
+            }
+            else if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
             else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
             hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
-            const int64_t spb = 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
+            const int64_t spb = h->generic ? 1 : 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
             for (int it = 0; it < I; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
+                if (h->generic)
+                    hipLaunchKernelGGL(glany::k_any_frames<false>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
+                                       b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, N, h->dt.windowd, h->dt.any);
+                else
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_frames_d<NN>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt));
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
                 hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
@@ -637,6 +701,7 @@ template <int N> static void launch_fft(gomel_handle* h, bool inverse, const flo
 
 static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_frames, float* out) {
     if (!h || !in || !out) return GOMEL_ERR_NULL;
+    if (h->generic) return GOMEL_ERR_UNSUPPORTED_N;   // register FFT cores only (Resolut 256 ... 4096, powers of two)
     if (n_frames == 0) return GOMEL_ERR_EMPTY;
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
@@ -683,7 +748,7 @@ const char* gomel_strerror(int s) {
     switch (s) {
         case GOMEL_OK: return "ok";
         case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax)";
-        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut must be 256, 512, 1024, 2048 or 4096";
+        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut not covered: even, a power of two up to 8192 or any length up to 4096 (FFT test hooks, fp32 I/O, phase and ISTFT write-back: 256 ... 4096 powers of two)";
         case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
         case GOMEL_ERR_EMPTY: return "empty input";
         case GOMEL_ERR_TABLE_RANGE: return "mel table indexes outside the band/bin range for this configuration";
@@ -858,7 +923,8 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     }
     // Path choice: the fused kernel walks consecutive frames per stream, which only pays once there are enough frames to fill
     // the chip (fused_min_frames); below that every frame in parallel (generic kernels) is faster.
-    b->precise = h->precision == 64 ? 1 : 0;
+    b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
+    if (h->generic && (b->io32 || b->want_spec)) return GOMEL_ERR_UNSUPPORTED_N;
     b->fast = (!b->precise && !b->want_spec && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     int rc = GOMEL_OK;
@@ -1216,6 +1282,7 @@ int gomel_irfft_frames(gomel_handle* h, const float* spectrum, size_t n_frames, 
 
 static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t n_pairs, float* mag_out) {
     if (!h || !mel || !mag_out) return GOMEL_ERR_NULL;
+    if (h->generic) return GOMEL_ERR_UNSUPPORTED_N;   // register FFT cores only (Resolut 256 ... 4096, powers of two)
     if (n_pairs == 0) return GOMEL_ERR_EMPTY;
     const int K = h->cfg.num_mels, N = h->cfg.resolut, H = N / 2;
     if (n_pairs % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
@@ -1300,6 +1367,10 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
         if (hipMemcpyAsync(d_wave + woff[u], wave[u], n_samples[u] * 8, hipMemcpyDefault, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc && hipMemcpyAsync(d_fx, fx.data(), tot_f * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     if (!rc) {
+        if (h->generic)
+            hipLaunchKernelGGL(glany::k_any_frames<true>, dim3((unsigned)tot_f), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, h->stream,
+                               d_wave, d_fx, (const double*)nullptr, (const double*)nullptr, d_smag, (int64_t)tot_f, N, h->dt.windowd, h->dt.any);
+        else
         GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
                               hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((tot_f + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_fx, d_smag, (int64_t)tot_f, hop, h->dt); });
         hipLaunchKernelGGL(k_domel_log, dim3((unsigned)tot_f), dim3(256), 0, h->stream, d_smag, h->dt.dom, d_out, K, H);
@@ -1342,6 +1413,7 @@ size_t gomel_phase_out_len(const gomel_config* c, int32_t num_freqs, size_t n_pa
 
 static int to_phase_guarded(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
     if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
+    if (h->generic) return GOMEL_ERR_UNSUPPORTED_N;   // register FFT cores only (Resolut 256 ... 4096, powers of two)
     const gomel_config& c = h->cfg;
     const int N = c.resolut, hop = c.window;
     if (n == 0) return GOMEL_ERR_EMPTY;
@@ -1377,6 +1449,7 @@ static int to_phase_guarded(gomel_handle* h, int32_t num_freqs, const double* wa
 static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_boost, const double* pairs, size_t n_pairs, double* out, size_t out_cap,
                      size_t* out_len) {
     if (!h || !pairs || !out) return GOMEL_ERR_NULL;
+    if (h->generic) return GOMEL_ERR_UNSUPPORTED_N;
     const gomel_config& c = h->cfg;
     const int N = c.resolut, hop = c.window;
     if (n_pairs == 0) return GOMEL_ERR_EMPTY;

@@ -289,6 +289,51 @@ def test_many_mel_bands_and_corrupted_table_blob(oracle):
     assert ei.value.status == 10
 
 
+# ------------------------------------------------------------------------------------------------ any Resolut (the reference: go-dsp radix-2 / Bluestein)
+@pytest.mark.parametrize("N,hop,K,fmax", [(8192, 2048, 96, 16000.0), (3000, 750, 64, 8000.0), (1000, 250, 40, 8000.0), (8, 3, 2, 8000.0), (64, 20, 8, 8000.0)])
+def test_any_frame_length_from_mel_to_mel_istft(oracle, N, hop, K, fmax):
+    """The reference takes any frame length (fft.FFTReal / fft.IFFT, mel/mel.go:95,116); outside 256 ... 4096 powers of two the
+    generic kernels (gl_any.hpp: radix-2 in LDS, Bluestein for the rest, fp64) carry FromMel, ToMel and ISTFT."""
+    import gomel_amd
+    fields = dict(NumMels=K, MelFmax=fmax, Window=hop, Resolut=N)
+    cfg = oracle.MelConfig(GriffinLimIterations=3, **fields)
+    m = mel_obj(fields, GriffinLimIterations=3)
+    F = 7
+    mel = oracle.random_logmel(F, K, seed=N)
+    x0 = oracle.x0_splitmix(N, oracle.out_len(cfg, len(mel)))
+    try:
+        want = oracle.from_mel(cfg, mel.copy(), x0)
+    except IndexError:
+        want = None                                                            # this geometry's undomel table runs off the bands: the reference panics
+    if want is None:
+        with pytest.raises(gomel_amd.GomelError):
+            m.FromMel(mel.copy(), x0=x0)
+    else:
+        got = m.FromMel(mel.copy(), x0=x0)
+        assert got.shape == want.shape and rms(got - want) < 1e-9 * max(1.0, rms(want)), rms(got - want)
+        outs = m.engine().from_mel_batch([mel, mel[:3 * K]], [x0, x0[:N + 2 * hop]], None)    # the batch entry point takes the same path
+        assert rms(outs[0] - want) < 1e-9 * max(1.0, rms(want))
+    sig = oracle.config2_signal(seconds=(15 * hop + 4 * hop + N) / 44100.0)
+    try:
+        wantm = oracle.to_mel(cfg, sig)
+    except IndexError:
+        wantm = None
+    if wantm is not None:
+        gotm = m.ToMel(sig)
+        assert gotm.shape == wantm.shape and np.max(np.abs(gotm - wantm)) < 1e-8
+
+    class STFT:
+        pass
+    s = STFT()
+    s.FrameShift, s.Window = hop, oracle.hann(N)
+    rng = np.random.default_rng(N)
+    spec = rng.uniform(0.1, 2.0, size=(5, N)) * np.exp(2j * np.pi * rng.uniform(size=(5, N)))
+    xi = oracle.x0_splitmix(2, N + 4 * hop)
+    wanti = oracle.istft_griffin_lim(s.Window, hop, spec.copy(), 2, xi)
+    goti = gomel_amd.ISTFT(s, [list(r) for r in spec], 2, x0=xi)               # (a list: no write-back requested of the generic path)
+    assert rms(goti - wanti) < 1e-9 * max(1.0, rms(wanti))
+
+
 # ------------------------------------------------------------------------------------------------ two processes, one GPU, real engines
 def _rank_main(rank, world, port, q):
     sys.path.insert(0, ROOT)

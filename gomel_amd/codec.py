@@ -239,3 +239,15 @@ def loadwav(name):
     except (OSError, ValueError, struct.error) as e:
         print(str(e))
         return np.zeros(0), 0.0
+
+
+def loadflac(name):
+    """mel/impl.go:266-296 (github.com/mewkiz/flac in the reference; gomel_amd/flac.py here): every sample of every subframe of every
+    frame, scaled by 1/(256*256) whatever the sample size; (empty, 0) with the error printed when the file cannot be decoded."""
+    from . import flac
+    try:
+        return flac.load(name)
+    except (OSError, ValueError, IndexError, struct.error) as e:
+        print(str(e))
+        return np.zeros(0), 0.0
+

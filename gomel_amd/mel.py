@@ -415,8 +415,14 @@ class Mel:
         osp = self.ToMel(buf)
         codec.dumpimage(outputFile, osp, self.NumMels, self.YReverse, float(len(buf) * self.NumMels) / float(len(osp)), float(sr))
 
+    # mel/mel.go:176-192
     def ToMelFlac(self, inputFile, outputFile):
-        raise NotImplementedError("FLAC decoding (mewkiz/flac) is outside the accelerated path; decode to WAV first")
+        from . import codec
+        buf, sr = codec.loadflac(inputFile)
+        if len(buf) == 0:
+            raise ErrFileNotLoaded()
+        osp = self.ToMel(buf)
+        codec.dumpimage(outputFile, osp, self.NumMels, self.YReverse, float(len(buf) * self.NumMels) / float(len(osp)), float(sr))
 
     # mel/mel.go:211-238
     def ToWavPng(self, inputFile, outputFile, x0=None, seed=None):
@@ -543,7 +549,9 @@ def LoadWav(inputFile):
 
 
 def LoadFlac(inputFile):
-    raise NotImplementedError("FLAC decoding is outside the accelerated path")
+    """mel/mel.go:155-158."""
+    from . import codec
+    return codec.loadflac(inputFile)[0]
 
 
 def SaveWav(outputFile, vec, sr):

@@ -109,6 +109,6 @@ def test_to_mel_flac_pipeline(tmp_path, oracle):
     out = tmp_path / "out.png"
     m.ToMelFlac(str(p), str(out))
     buf, samples, sr = codec.loadpng(str(out), m.YReverse)
-    assert sr == 22050.0 and len(buf) == len(m.ToMel(np.array(pcm, dtype=np.float64) / 65536.0))
+    assert sr == float(np.float16(22050.0)) and len(buf) == len(m.ToMel(np.array(pcm, dtype=np.float64) / 65536.0))   # the PNG metadata is float16 (impl.go:120-125)
     with pytest.raises(gomel_amd.ErrFileNotLoaded):
         m.ToMelFlac(str(tmp_path / "nothing.flac"), str(out))

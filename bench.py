@@ -348,6 +348,10 @@ def main():
 
     # device-side figures (outside the timed region): one BLOCK resident in HBM
     res_fps, tm = resident(engine, fields, min(n_utt, BLOCK), frames, first, max(3, min(args.steps, 10)))
+    # inside the timed region the library cuts a call into chunks (min(16, frames / 12288), gomel_hip.hip): the same kernel at the chunk's size
+    nb = min(n_utt, BLOCK)
+    n_chunks = min(16, max(1, nb * frames // 12288), nb)
+    tm_chunk = resident(engine, fields, -(-nb // n_chunks), frames, first, 3)[1] if n_chunks > 1 else tm
 
     side = rank == 0 and world == 1 and not args.no_single           # side measurements: N = 1 only
     single = pageable = cfg1 = None
@@ -397,6 +401,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
                          "algorithmic_bytes_per_launch": bytes_launch,
+                         "launch": "one launch over the whole %d-utterance batch (the configuration as BASELINE names it), HIP events on the library's stream in this process" % min(n_utt, BLOCK),
+                         "timed_region_launches": {"what": "the same kernel at the size the host-to-host call launches it (%d chunks per call, copy/compute overlap)" % n_chunks,
+                                                   "frames_per_launch": tm_chunk["frames"], "launch_ms": tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]),
+                                                   "frac": tm_chunk["frames"] * algorithmic_bytes_per_frame_iter(N, hop) / (tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "whole_job_frac_resident": res_fps * per_frame_bytes / 1e9 / HBM_PEAK_GBS,
                          "whole_job_frac_host_to_host": value / world * per_frame_bytes / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,

@@ -637,19 +637,26 @@ __global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wav
     if (is0) { out[0] = fabs(dc.x + dc.y); out[G::C] = fabs(dc.x - dc.y); }
 }
 
-// domel (mel/impl.go:310-345) + spectral_normalize (mel/impl.go:410-419): one block per frame, one thread per band.
+// domel (mel/impl.go:310-345) + spectral_normalize (mel/impl.go:410-419): one block per frame.  The frame's N/2+1 magnitudes are
+// staged in LDS with coalesced loads first (a band's row walks a run of bins: straight from global memory every thread strode
+// through its own run -- 1.0 TB/s; from LDS the kernel is bound by the 16 KB it reads and the 3 KB it writes per frame).
 __global__ __launch_bounds__(256) void k_domel_log(const double* __restrict__ smag, const BinRow* __restrict__ dom, double* __restrict__ out,
                                                    int K, int H) {
+    extern __shared__ double m_sh[];                      // [H + 1]
     const int64_t f = blockIdx.x;
     const double* m = smag + f * (H + 1);
+    for (int k = threadIdx.x; k <= H; k += blockDim.x) m_sh[k] = m[k];
+    __syncthreads();
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         const BinRow r = dom[i];
+        double2 o;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            double v = apply_row(r, m + c);  // channel 1 is the same spectrum one bin up: |S[N-1-j]| = |S[j+1]|
+            double v = apply_row(r, m_sh + c);  // channel 1 is the same spectrum one bin up: |S[N-1-j]| = |S[j+1]|
             if (v < 1e-5) v = 1e-5;
-            out[(f * K + i) * 2 + c] = log(v);
+            (c ? o.y : o.x) = log(v);
         }
+        reinterpret_cast<double2*>(out)[f * K + i] = o;
     }
 }
 

@@ -1373,7 +1373,7 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
         else
         GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
                               hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((tot_f + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_fx, d_smag, (int64_t)tot_f, hop, h->dt); });
-        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)tot_f), dim3(256), 0, h->stream, d_smag, h->dt.dom, d_out, K, H);
+        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)tot_f), dim3(256), (size_t)(H + 1) * 8, h->stream, d_smag, h->dt.dom, d_out, K, H);
         for (size_t u = 0; u < n_utt && !rc; u++)
             if (hipMemcpyAsync(out_pairs[u], d_out + foff[u] * (size_t)K * 2, F[u] * (size_t)K * 16, hipMemcpyDefault, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
         if (hipStreamSynchronize(h->stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;   // also: fx must outlive its copy

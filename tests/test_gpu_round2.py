@@ -289,6 +289,64 @@ def test_many_mel_bands_and_corrupted_table_blob(oracle):
     assert ei.value.status == 10
 
 
+def test_chunked_pipeline_on_a_ragged_batch(oracle):
+    """gomel_from_mel_batch cuts big calls into chunks that cycle through three sets of device buffers (upload c+1 / compute c /
+    download c-1): a ragged 300-utterance batch (3 ... 700 frames, 8+ chunks), explicit x0 for some utterances, against the same
+    utterances computed one batch-resident call at a time."""
+    import gomel_amd
+    fields = dict(S, GriffinLimIterations=4)
+    m = mel_obj(fields)
+    e = m.engine()
+    rng = np.random.default_rng(11)
+    frames = rng.integers(3, 700, size=300).tolist()
+    mels = [oracle.random_logmel(f, 80, seed=i) for i, f in enumerate(frames)]
+    x0s = [oracle.x0_splitmix(77 + i, e.out_len(len(mm))) if i % 3 == 0 else None for i, mm in enumerate(mels)]
+    seeds = [500 + i for i in range(len(mels))]
+    got = e.from_mel_batch(mels, x0s, seeds)
+    assert [len(g) for g in got] == [e.out_len(len(mm)) for mm in mels] and all(np.isfinite(g).all() for g in got)
+    again = e.from_mel_batch(mels, x0s, seeds)
+    assert all(np.array_equal(a, b) for a, b in zip(got, again))                # deterministic, buffers recycled correctly
+    for lo in range(0, 300, 60):                                                # reference: small resident batches, no chunking
+        b = gomel_amd.Batch(e, [len(mm) for mm in mels[lo:lo + 60]])
+        b.upload(mels[lo:lo + 60], x0s[lo:lo + 60], seeds[lo:lo + 60])
+        b.run()
+        ref = b.download()
+        b.close()
+        for a, r in zip(got[lo:lo + 60], ref):
+            assert rms(a - r) < 1e-5                                            # same kernels, other segmentation: rounding only
+    cfg = oracle.MelConfig(**fields)
+    for i in (0, 1, 150, 299):
+        x0 = x0s[i] if x0s[i] is not None else oracle.x0_splitmix(seeds[i], len(got[i]))
+        assert rms(got[i] - oracle.from_mel(cfg, mels[i].copy(), x0)) < RMS_TOL
+
+
+def test_concurrent_batch_calls_on_one_handle(oracle):
+    """Four host threads push chunked batch calls through ONE handle at the same time (the handle's mutex is taken per stage,
+    batches are created and destroyed between stages): every call must come back complete and equal to the serial result."""
+    import threading
+    fields = dict(S, GriffinLimIterations=3)
+    m = mel_obj(fields)
+    e = m.engine()
+    sets = [[oracle.random_logmel(150 + 10 * t + j, 80, seed=100 * t + j) for j in range(120)] for t in range(4)]
+    serial = [e.from_mel_batch(ms, None, list(range(len(ms)))) for ms in sets]
+    out, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            out[t] = e.from_mel_batch(sets[t], None, list(range(len(sets[t]))))
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for t in range(4):
+        assert all(np.array_equal(a, b) for a, b in zip(out[t], serial[t]))
+
+
 # ------------------------------------------------------------------------------------------------ any Resolut (the reference: go-dsp radix-2 / Bluestein)
 @pytest.mark.parametrize("N,hop,K,fmax", [(8192, 2048, 96, 16000.0), (3000, 750, 64, 8000.0), (1000, 250, 40, 8000.0), (8, 3, 2, 8000.0), (64, 20, 8, 8000.0)])
 def test_any_frame_length_from_mel_to_mel_istft(oracle, N, hop, K, fmax):

@@ -1088,8 +1088,10 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
         if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
         total_frames += (int64_t)(n_pairs[u] / (size_t)K);
     }
-    // chunk plan: at least ~12k frames per chunk (half a round of the chip: the kernels still run at 2.3 of the 2.6 M frames/s
-    // of a big batch, scripts/chunk_probe.py, and more chunks expose less of the first upload / last download), at most 16
+    // Chunk plan: equal chunks of at least ~12k frames (half a round of the chip: the kernels still run at 2.3 of the 2.6 M
+    // frames/s of a big launch, and more chunks expose less of the first upload / last download), at most 16.  Measured and
+    // dropped: small chunks at both ends and big ones in the middle (shares 1:4:7:3:1) -- a pipeline model says 46 ms against 49
+    // for eight equal chunks at config 3, the hardware says 50.3 (scripts/chunk_probe.py).
     const int64_t kMinChunkFrames = 12288;
     int n_chunks = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
     if (const char* e = getenv("GOMEL_CHUNKS")) { int v = atoi(e); if (v > 0) n_chunks = std::min(v, 64); }   // tuning knob

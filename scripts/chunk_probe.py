@@ -34,5 +34,6 @@ def run(mode, U, **env):
     r = subprocess.run([sys.executable, __file__, "child", mode, str(U)], env=e, capture_output=True, text=True)
     print((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1], flush=True)
 for U in (256, 32): run("resident", U)
-for ch in (0, 4, 8, 12, 16): run("h2h", 256, **({"GOMEL_CHUNKS": ch} if ch else {}))
+for ch in (0, 8, 5): run("h2h", 256, **({"GOMEL_CHUNKS": ch} if ch else {}))
+for U in (64, 128, 512): run("h2h", U)
 run("h2h", 1024)

@@ -63,6 +63,9 @@ template <class V> struct Twiddles {
     const V* tw1;  // [R1][C1]  W_C^{t1 q1}
     const V* tw2;  // [R2][8]   W_{C1}^{t2 q2}
     const V* wn;   // [C]       W_N^k
+    const V* w2r = nullptr;  // optional: THIS lane's 16 pass-2 twiddles (index u*R2 + q) already in registers -- they depend on
+                             // the lane only, so a kernel that walks many frames loads them once (k_gl_fused) instead of 30 LDS
+                             // reads per frame (forward + inverse)
 };
 
 // ---------------------------------------------------------------------------------------------- complex helpers
@@ -328,7 +331,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
     for (int u = 0; u < G::NB2; u++) {
         const int t2 = (t + G::T * u) / G::R1;
 #pragma unroll
-        for (int q = 1; q < G::R2; q++) w2[u * G::R2 + q] = tw.tw2[q * 8 + t2];
+        for (int q = 1; q < G::R2; q++) w2[u * G::R2 + q] = tw.w2r ? tw.w2r[u * G::R2 + q] : tw.tw2[q * 8 + t2];
     }
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) dftR<false, G::R2, 1>(&v[u * G::R2]);
@@ -374,7 +377,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v
 #pragma unroll
         for (int q = 0; q < G::R2; q++) {
             v[u * G::R2 + q] = lds[t2 * G::SB + q1 + G::R1 * q];
-            if (q) w2[q] = tw.tw2[q * 8 + t2];
+            if (q) w2[q] = tw.w2r ? tw.w2r[u * G::R2 + q] : tw.tw2[q * 8 + t2];
         }
         apply_tw<true, 1, G::R2>(&v[u * G::R2], w2);
     }

@@ -63,6 +63,8 @@ template <class V> struct Twiddles {
     const V* tw1;  // [R1][C1]  W_C^{t1 q1}
     const V* tw2;  // [R2][8]   W_{C1}^{t2 q2}
     const V* wn;   // [C]       W_N^k
+    const V* w1r = nullptr;  // optional: THIS lane's pass-1 twiddles (index u + NB1*q) for q <= w1r_n, same idea as w2r; the rest from tw1
+    int w1r_n = 0;
     const V* w2r = nullptr;  // optional: THIS lane's 16 pass-2 twiddles (index u*R2 + q) already in registers -- they depend on
                              // the lane only, so a kernel that walks many frames loads them once (k_gl_fused) instead of 30 LDS
                              // reads per frame (forward + inverse)
@@ -302,7 +304,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 #pragma unroll
     for (int u = 0; u < G::NB1; u++)
 #pragma unroll
-        for (int q = 1; q < G::R1; q++) w1[u + G::NB1 * q] = tw.tw1[q * G::C1 + t + G::T * u];
+        for (int q = 1; q < G::R1; q++) w1[u + G::NB1 * q] = (tw.w1r && q <= tw.w1r_n) ? tw.w1r[u + G::NB1 * q] : tw.tw1[q * G::C1 + t + G::T * u];
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<false, G::R1, G::NB1>(&v[u]);
     __builtin_amdgcn_sched_barrier(0);   // keep the twiddle reads above the butterfly: they land while it computes
@@ -399,7 +401,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v
 #pragma unroll
         for (int q = 0; q < G::R1; q++) {
             v[u + G::NB1 * q] = lds[q * G::SAI + t1];
-            if (q) w1[G::NB1 * q] = tw.tw1[q * G::C1 + t1];
+            if (q) w1[G::NB1 * q] = (tw.w1r && q <= tw.w1r_n) ? tw.w1r[u + G::NB1 * q] : tw.tw1[q * G::C1 + t1];
         }
         apply_tw<true, G::NB1, G::R1>(&v[u], w1);
     }

@@ -344,6 +344,12 @@ struct SegDesc {
 };
 
 constexpr int kFusedThreads = 256;
+// Per-geometry register budget of k_gl_fused (254-256 VGPRs everywhere): how many pass-1 twiddles stay in registers, and whether
+// the next frame's rows are requested before the forward FFT (N 4096: the inverse FFT alone does not cover their HBM latency) or
+// after the spectral step (shorter live range: room for the twiddles).  Chosen so that no instantiation spills (hipcc -S audit).
+constexpr int fused_w1_keep(int n, int sh) { return n >= 4096 ? (sh >= 8 ? 15 : sh >= 4 ? 11 : 0) : (n >= 2048 && sh <= 1) ? 0 : 15; }
+constexpr bool fused_late_rows(int n) { return n <= 2048; }
+constexpr bool fused_w2_regs(int n, int sh) { return !(n >= 4096 && sh <= 2); }   // hop = N/16, N/8 at N 4096: the 14-15 row accumulator leaves no room
 constexpr int kMaxSegFrames = 64;   // a wave fetches the Nyquist magnitudes of all its segment's frames with ONE load (lane = frame)
 
 // Lane-pair form of two consecutive rows.  A row is T sample pairs, one per lane (8 bytes): as such it moves with dwordx2
@@ -391,7 +397,15 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     for (int u = 0; u < G::NB2; u++)
 #pragma unroll
         for (int q = 0; q < G::R2; q++) w2r[u * G::R2 + q] = tb.tw2[q * 8 + ((int)(threadIdx.x % G::T) + G::T * u) / G::R1];
-    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr, w2r};
+    // ... and as many of its pass-1 twiddles as the register file takes without spilling (W1_KEEP of the R1-1, by geometry:
+    // the pass-1 peak already holds them as temporaries, so keeping them costs registers only outside that peak): -1.5 ... -2 %
+    constexpr int W1_KEEP = fused_w1_keep(N, SH);
+    v2f w1r[16];
+#pragma unroll
+    for (int u = 0; u < G::NB1; u++)
+#pragma unroll
+        for (int q = 0; q < G::R1; q++) w1r[u + G::NB1 * q] = q <= W1_KEEP ? tb.tw1[q * G::C1 + (int)(threadIdx.x % G::T) + G::T * u] : v2f{0.f, 0.f};
+    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr, W1_KEEP ? w1r : nullptr, W1_KEEP, fused_w2_regs(N, SH) ? w2r : nullptr};
         // Exchange synchronisation.  A stream of T <= 64 lanes lives inside ONE wave, whose LDS operations execute in program
     // order: its exchanges need no s_barrier, only a compiler-level fence so that loads/stores are not reordered.  Wider
     // streams (N = 4096: two waves) use the workgroup barrier.
@@ -496,31 +510,35 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= xin[j];
         st.mark(17);
-        // slide the input window now: the next frame's SH new rows (hop samples) load behind the two FFTs, two rows per
-        // dwordx4; the loaded values stay RAW until the inverse FFT is done, so nothing waits for them here
-#pragma unroll
-        for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];
+        // The next frame's SH new rows (hop samples), two rows per dwordx4, and -- in the last frames of a segment with a
+        // successor -- the successor's head from the tail buffer (rare: behind a wave-uniform branch).  The loaded values stay RAW
+        // until the inverse FFT is done, so nothing waits for them where they are issued: before the forward FFT at N 4096 (the
+        // inverse FFT alone does not cover their HBM latency there), after the spectral step otherwise (shorter live range: the
+        // registers go to the pass-1 twiddles).
         const bool more = g + 1 < d.G;
         const int row0 = (g + 1) * SH + KEEP;                                // first of the SH new rows
+        const bool any_next = more && d.has_next && row0 + SH - 1 >= rows_owned;
         v4f xq[NPAIR > 0 ? NPAIR : 1];
         v2f xs = v2f{0.f, 0.f};
-#pragma unroll
-        for (int pq = 0; pq < NPAIR; pq++)
-            xq[pq] = *reinterpret_cast<const v4f*>(xin_p + T * (more ? row0 + 2 * pq : 0) + lane_off);   // clamped: unused when !more
-        if constexpr (SH & 1) xs = xin_p[T * (more ? row0 + SH - 1 : 0) + t];
-        // rows past the owned range (the last frames of a segment with a successor) also take the successor's head from the tail
-        // buffer: rare, so behind a (wave-uniform for T >= 64) branch instead of SH more loads in every frame
-        const bool any_next = more && d.has_next && row0 + SH - 1 >= rows_owned;
         v2f tl[SH];          // (read only under any_next: no zero-fill of 3 SH registers in every frame)
         float fl[SH];
-        if (any_next) {
+        auto issue_rows = [&] {
 #pragma unroll
-            for (int jj = 0; jj < SH; jj++) {
-                const bool in_next = row0 + jj >= rows_owned;
-                tl[jj] = town[T * (in_next ? row0 + jj - rows_owned : 0) + t];
-                fl[jj] = in_next ? 1.f : 0.f;
+            for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];             // slide the input window
+#pragma unroll
+            for (int pq = 0; pq < NPAIR; pq++)
+                xq[pq] = *reinterpret_cast<const v4f*>(xin_p + T * (more ? row0 + 2 * pq : 0) + lane_off);   // clamped: unused when !more
+            if constexpr (SH & 1) xs = xin_p[T * (more ? row0 + SH - 1 : 0) + t];
+            if (any_next) {
+#pragma unroll
+                for (int jj = 0; jj < SH; jj++) {
+                    const bool in_next = row0 + jj >= rows_owned;
+                    tl[jj] = town[T * (in_next ? row0 + jj - rows_owned : 0) + t];
+                    fl[jj] = in_next ? 1.f : 0.f;
+                }
             }
-        }
+        };
+        if constexpr (!fused_late_rows(N)) issue_rows();
         st.mark(15);
         fft_forward<G>(v, my, t, tw, sync, st);
         {
@@ -529,6 +547,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             spectral_apply<G>(v, t, mr, wn);
         }
         st.mark(7);
+        if constexpr (fused_late_rows(N)) issue_rows();
         fft_inverse<G>(v, my, t, tw, sync, st);
         // The next frame's rows: unpacked BEFORE this frame's stores are issued.  vmcnt counts loads and stores in issue order,
         // so a wait placed behind the (conditional) stores below would have to drain them too -- a full store round trip at the

@@ -18,8 +18,9 @@ def isa(tmp_path_factory):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     out = str(tmp_path_factory.mktemp("isa") / "gomel.s")
-    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-S", "--cuda-device-only", "-o", out, SRC],
-                   check=True, stderr=subprocess.DEVNULL)
+    # the product's flags (gomel_amd/build.py), so that what is audited is what ships
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt",
+                    "-S", "--cuda-device-only", "-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
     return [l.rstrip() for l in open(out)]
 
 
@@ -87,15 +88,16 @@ def test_asm_blocks_never_consume_an_opsel_result_in_the_next_instruction(isa):
     assert not bad, bad[:5]
 
 
-def test_fused_kernel_loop_has_no_scratch_traffic_for_the_bench_geometry(isa):
-    name = "_Z10k_gl_fusedILi4096ELi5EE"
-    start = next(i for i, l in enumerate(isa) if l.startswith(name) and ":" in l)
-    end = next(i for i in range(start, len(isa)) if "s_endpgm" in isa[i])
-    body = isa[start:end]
-    mags = [i for i, l in enumerate(body) if "global_load_dwordx4" in l]
-    assert len(mags) >= 4                          # the four 16-byte magnitude loads of the lane-slot layout
-    stores = [i for i, l in enumerate(body) if "global_store_dwordx2" in l]
-    loop = body[mags[-4] - 10: stores[4] + 1]      # top of a frame ... the frame's five finished rows stored
-    assert len(loop) > 1000
-    assert not any("scratch_" in l for l in loop), "spill in the steady-state loop of k_gl_fused<4096,5>"
-    assert not any(l.strip().startswith("flat_") for l in body), "a global access degraded to flat_"
+def test_no_fused_kernel_instantiation_spills(isa):
+    """k_gl_fused runs at 2 waves per SIMD on 224-256 VGPRs: how many twiddles each geometry keeps in registers is chosen per
+    instantiation (fused_w1_keep / fused_w2_regs / fused_late_rows) so that NONE of the 25 spills; a spill would put scratch traffic
+    into the frame loop.  The kernel metadata of the compiled code object says so directly."""
+    text = "\n".join(isa)
+    found = re.findall(r"\.name:\s+(_Z10k_gl_fusedILi(\d+)ELi(\d+)E\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(found) == 25, len(found)
+    for name, n, sh, vgpr, spill in found:
+        assert int(spill) == 0 and int(vgpr) <= 256, (n, sh, vgpr, spill)
+    body = isa[next(i for i, l in enumerate(isa) if l.startswith("_Z10k_gl_fusedILi4096ELi5EE") and ":" in l):]
+    body = body[:next(i for i, l in enumerate(body) if "s_endpgm" in l)]
+    assert not any("scratch_" in l for l in body)
+    assert sum("global_load_dwordx4" in l for l in body) >= 6      # four magnitude loads + two row pairs per frame

@@ -15,6 +15,19 @@ int main(void) {
     if (gomel_to_mel_pairs(&c, 441000) != (size_t)342 * 192) return 5;
     if (gomel_phase_pairs(&c, 768, 441000) != (size_t)342 * 768 || gomel_phase_out_len(&c, 768, (size_t)342 * 768) != 440576) return 6;
     if (strcmp(gomel_strerror(GOMEL_OK), "ok") != 0 || gomel_abi_version() != GOMEL_HIP_ABI_VERSION) return 7;
+    /* ABI v2 entry points as a C caller sees them: the generic-length gate, the table builder, the multi-handle batch call's
+     * argument checks -- all of it without a GPU */
+    c.resolut = 3000; if (gomel_tables_bytes_for(&c) == 0) return 10;            /* any even length up to 4096 */
+    c.resolut = 3001; if (gomel_tables_bytes_for(&c) != 0) return 11;            /* odd: refused */
+    c.resolut = 8192; if (gomel_tables_bytes_for(&c) == 0) return 12;
+    c.resolut = 4096;
+    {
+        const double* mel[1] = {NULL}; double* out[1] = {NULL}; size_t np[1] = {192};
+        if (gomel_from_mel_batch_multi(NULL, 1, 1, mel, np, NULL, NULL, out, NULL) != GOMEL_ERR_NULL) return 13;
+        if (gomel_istft_spec(NULL, NULL, 1, 1, NULL, 0, NULL, 0, NULL, NULL) != GOMEL_ERR_NULL) return 14;
+        if (gomel_to_mel_batch(NULL, 1, mel, np, out, NULL, NULL) != GOMEL_ERR_NULL) return 15;
+        if (gomel_host_free(NULL) != GOMEL_OK || gomel_host_register(NULL, 16) != GOMEL_ERR_NULL) return 16;
+    }
     gomel_handle* h = NULL;
     int rc = gomel_create(&c, &h);
     if (gomel_device_count() == 0) {

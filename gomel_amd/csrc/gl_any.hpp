@@ -4,6 +4,7 @@
 // Bluestein's chirp-z otherwise.  The tuned kernels (gl_fft.hpp) exist for N = 256 ... 4096; everything else that is even and
 //   * a power of two up to 8192, or
 //   * any length up to 4096 (Bluestein through a power-of-two convolution of M >= 2N-1 <= 8192 points)
+// (odd lengths included: Bluestein does not care, and the reference's index arithmetic for an odd N is followed bin by bin)
 // runs here: one 1024-thread workgroup per frame, the frame as M complex doubles in LDS (up to 128 KiB of the CU's 160),
 // plain in-place radix-2 passes -- decimation in frequency forward (natural in, bit-reversed out) and decimation in time inverse
 // (bit-reversed in, natural out), so no permutation pass is ever needed.  The arithmetic follows the reference's LITERAL form:
@@ -107,15 +108,21 @@ __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __rest
         for (int k = threadIdx.x; k <= H; k += kAnyThreads) { const v2d s = buf[pos(k)]; o[k] = hypot(s.x, s.y); }
         return;
     }
-    // mel/mel.go:98-102 on bins 0 ... N/2 (their magnitudes survive), then the conjugate fill of :105-108
-    for (int k = threadIdx.x; k <= H; k += kAnyThreads) {
+    // mel/mel.go:98-102 on the bins whose magnitudes survive the conjugate fill of :105-108 (j = 1 ... N/2 - 1 -> N - j).
+    // Even N: bins 0 ... N/2, bin N/2 carrying channel 1's last bin (undospectrum puts ch1[j] at N-1-j, mel/impl.go:402-403).
+    // Odd N = 2H+1: bins 0 ... H-1 from channel 0, bin H is never written by undospectrum (magnitude 0), and bin H+1 = N-H --
+    // out of the fill's reach -- keeps channel 1's last bin WITH ITS OWN PHASE; the spectrum is then not Hermitian and the
+    // reference simply takes the real part of the inverse (mel/mel.go:120), as the last line of this kernel does.
+    const bool odd = (N & 1) != 0;
+    const int own_top = odd ? H + 1 : H;                 // highest bin that keeps a magnitude of its own
+    for (int k = threadIdx.x; k <= own_top; k += kAnyThreads) {
         const int p = pos(k);
-        const double m = k < H ? mag[frame * H + k] : nyq[frame];
+        const double m = k < H ? mag[frame * H + k] : (k == own_top ? nyq[frame] : 0.0);
         const v2d u = unit_phase_any(buf[p]);
         buf[p] = v2d{u.x * m, u.y * m};
     }
     __syncthreads();
-    for (int k = H + 1 + threadIdx.x; k < N; k += kAnyThreads) buf[pos(k)] = conjd(buf[pos(N - k)]);
+    for (int k = own_top + 1 + threadIdx.x; k < N; k += kAnyThreads) buf[pos(k)] = conjd(buf[pos(N - k)]);
     __syncthreads();
     if (at.bluestein) {   // inverse DFT = conj(forward DFT(conj(.)))
         for (int k = threadIdx.x; k < N; k += kAnyThreads) buf[k] = conjd(buf[k]);

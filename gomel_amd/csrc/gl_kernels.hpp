@@ -49,9 +49,9 @@ struct DevTables {
         default:   { constexpr int NN = 256;  __VA_ARGS__; } break; \
     }
 static inline bool gomel_supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-// what gl_any.hpp covers besides: even lengths that are a power of two up to 8192, or anything up to 4096 (Bluestein, M <= 8192)
+// what gl_any.hpp covers besides: powers of two up to 8192, and any length (odd ones too) up to 4096 (Bluestein, M <= 8192)
 static inline bool gomel_generic_n(int n) {
-    if (n < 4 || (n & 1) || gomel_supported_n(n)) return false;
+    if (n < 4 || gomel_supported_n(n)) return false;
     const bool pow2 = (n & (n - 1)) == 0;
     return pow2 ? n <= 8192 : n <= 4096;
 }

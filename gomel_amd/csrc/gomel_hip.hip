@@ -748,7 +748,7 @@ const char* gomel_strerror(int s) {
     switch (s) {
         case GOMEL_OK: return "ok";
         case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax)";
-        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut not covered: even, a power of two up to 8192 or any length up to 4096 (FFT test hooks, fp32 I/O, phase and ISTFT write-back: 256 ... 4096 powers of two)";
+        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut not covered: a power of two up to 8192 or any length up to 4096 (FFT test hooks, fp32 I/O, phase and ISTFT write-back: 256 ... 4096 powers of two; ISTFT: even lengths)";
         case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
         case GOMEL_ERR_EMPTY: return "empty input";
         case GOMEL_ERR_TABLE_RANGE: return "mel table indexes outside the band/bin range for this configuration";
@@ -1252,6 +1252,7 @@ static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, i
     const size_t L = (size_t)h->cfg.resolut + (n_frames - 1) * (size_t)h->cfg.window;   // mel/mel.go:80
     if (out_cap < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
     gomel_batch* b = nullptr;
+    if (h->cfg.resolut & 1) return GOMEL_ERR_UNSUPPORTED_N;   // odd N: bins N/2 AND N/2+1 keep magnitudes of their own in the exported ISTFT; the [N/2+1] interface cannot carry both
     const bool spec = spec_out && iterations > 0;   // zero iterations: the loop never runs, the spectrogram is left as it was
     int rc = batch_create_common(h, 1, &n_frames, BF_DIRECT | (spec ? BF_SPEC : 0), iterations, &b);
     if (rc) return rc;

@@ -17,8 +17,9 @@ int main(void) {
     if (strcmp(gomel_strerror(GOMEL_OK), "ok") != 0 || gomel_abi_version() != GOMEL_HIP_ABI_VERSION) return 7;
     /* ABI v2 entry points as a C caller sees them: the generic-length gate, the table builder, the multi-handle batch call's
      * argument checks -- all of it without a GPU */
-    c.resolut = 3000; if (gomel_tables_bytes_for(&c) == 0) return 10;            /* any even length up to 4096 */
-    c.resolut = 3001; if (gomel_tables_bytes_for(&c) != 0) return 11;            /* odd: refused */
+    c.resolut = 3000; if (gomel_tables_bytes_for(&c) == 0) return 10;            /* any length up to 4096 */
+    c.resolut = 3001; if (gomel_tables_bytes_for(&c) == 0) return 11;            /* odd lengths too */
+    c.resolut = 6000; if (gomel_tables_bytes_for(&c) != 0) return 17;            /* not a power of two above 4096: refused */
     c.resolut = 8192; if (gomel_tables_bytes_for(&c) == 0) return 12;
     c.resolut = 4096;
     {

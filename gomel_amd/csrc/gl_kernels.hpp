@@ -605,6 +605,180 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #endif
 }
 
+// =============================================================================================== fused path, fp64 ("64-bit mode")
+// The same sliding-window kernel in double precision: what makes 64-bit mode (the only mode that agrees with the reference's fp64
+// arithmetic on EVERY input) affordable.  Same segments, same ownership / tail rule, same lane-slot magnitude
+// rows (double), same FFT core (its C++ forms: the packed-math asm blocks are fp32-only).  Differences forced by the type: one
+// wave per SIMD (launch_bounds(256, 1): ~330 VGPRs -- 16 complex doubles of frame data, 16 of input window, the accumulator,
+// magnitudes, twiddles), all LDS dynamic (136 KB at N 4096: exchange areas + TW1 + TW2 + window in double), a lane's sample pair
+// is already 16 bytes (plain dwordx4 loads / stores, no DPP row pairing).  Algorithmic bytes per frame-iteration: twice the fp32
+// kernel's.  The fp64 vector unit runs at half the fp32 rate and packs nothing, so expect ~2.3x the fp32 time.
+struct MagRawD { double a[16]; double nq; };
+template <class G> GL_DEV void load_mag_rows_d(MagRawD& r, int t, const double* __restrict__ mag_row) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) r.a[e] = mag_row[((e / 4) * G::T + t) * 4 + (e % 4)];
+}
+GL_DEV void finish_mags_d(MagRegsD& m, const MagRawD& r, bool is0) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) { m.ma[e] = r.a[e]; m.mb[e] = r.a[8 + e]; }
+    m.m0 = is0 ? m.mb[0] : 0.0;
+    m.mn = is0 ? r.nq : 0.0;
+    m.mb[0] = is0 ? m.ma[0] : m.mb[0];
+}
+
+template <int N, int SH>
+__global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* __restrict__ x_in, const double* __restrict__ tail_in,
+                                                                double* __restrict__ x_out, double* __restrict__ tail_out,
+                                                                const SegDesc* __restrict__ segs, int n_segs, int g_max,
+                                                                const double* __restrict__ mag, const double* __restrict__ nyq, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = kFusedThreads / T, KEEP = 16 - SH, TAIL_PAIRS = KEEP * T;
+    extern __shared__ __attribute__((aligned(16))) char fused_d_smem[];
+    v2d* lds = reinterpret_cast<v2d*>(fused_d_smem);      // [STREAMS * LDS_SLOTS | TW1 | TW2 | window pairs | STREAMS ints]
+    v2d* tw1_l = lds + STREAMS * G::LDS_SLOTS;
+    v2d* tw2_l = tw1_l + G::TW1_N;
+    v2d* win_l = tw2_l + G::TW2_N;
+    int* g_sh = reinterpret_cast<int*>(win_l + G::C);
+    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
+    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
+    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
+    __syncthreads();
+    const Twiddles<v2d> tw{tw1_l, tw2_l, nullptr};
+    auto sync = [] {
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    int seg = blockIdx.x * STREAMS + stream;
+    const bool live = seg < n_segs;
+    if (!live) seg = n_segs - 1;
+    SegDesc d = segs[seg];
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    if constexpr (T >= 64) {
+        d.G = __builtin_amdgcn_readfirstlane(d.G);
+        d.has_prev = __builtin_amdgcn_readfirstlane(d.has_prev);
+        d.has_next = __builtin_amdgcn_readfirstlane(d.has_next);
+        seg = __builtin_amdgcn_readfirstlane(seg);
+    }
+    constexpr bool WU = (T >= 64);
+    auto uo = [](long long v) { if constexpr (WU) return uniform_i64(v); else return v; };
+    const int seg_prev = d.has_prev ? seg - 1 : seg;
+    const v2d* xin_p = reinterpret_cast<const v2d*>(x_in) + uo(d.s0 / 2);
+    v2d* xout_p = reinterpret_cast<v2d*>(x_out) + uo(d.s0 / 2);
+    const v2d* tprev = reinterpret_cast<const v2d*>(tail_in) + uo((int64_t)seg_prev * TAIL_PAIRS);
+    const v2d* town = reinterpret_cast<const v2d*>(tail_in) + uo((int64_t)seg * TAIL_PAIRS);
+    v2d* tout = reinterpret_cast<v2d*>(tail_out) + uo((int64_t)seg * TAIL_PAIRS);
+    const double* mag_p = mag + uo(d.frame0 * G::C);
+    const double* nyq_p = nyq + uo(d.frame0);
+    const double f_prev = d.has_prev ? 1.0 : 0.0, f_next = d.has_next ? 1.0 : 0.0;
+    const int rows_owned = d.G * SH;
+    if constexpr (STREAMS > 1) {
+        if (t == 0) g_sh[stream] = live ? d.G : 0;
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < STREAMS; i++) m = max(m, g_sh[i]);
+        g_max = m;
+    } else {
+        g_max = d.G;
+    }
+    v2d xin[16], acc[KEEP], wn[8];
+    const v2d* wl = win_l + t;
+    load_wn<G>(wn, t, tb.wnd);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        v2d a = xin_p[T * j + t];
+        if (j < KEEP) a += tprev[T * j + t] * f_prev;
+        const int rn = j >= rows_owned ? j - rows_owned : 0;
+        a += town[T * rn + t] * (j >= rows_owned ? f_next : 0.0);
+        xin[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < KEEP; j++) acc[j] = v2d{0.0, 0.0};
+
+    for (int g = 0; g < g_max; g++) {
+        const bool active = live && g < d.G;
+        const int gg = g < d.G ? g : d.G - 1;
+        MagRawD mraw;                                                         // issued now, finished after the forward FFT
+        load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
+        mraw.nq = nyq_p[gg];
+        v2d v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = wl[T * j] * xin[j];
+#pragma unroll
+        for (int j = 0; j < KEEP; j++) xin[j] = xin[j + SH];
+        const bool more = g + 1 < d.G;
+        const int row0 = (g + 1) * SH + KEEP;
+        const bool any_next = more && d.has_next && row0 + SH - 1 >= rows_owned;
+        v2d xl[SH], tl[SH];
+        double fl[SH];
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) xl[jj] = xin_p[T * (more ? row0 + jj : 0) + t];
+        if (any_next) {
+#pragma unroll
+            for (int jj = 0; jj < SH; jj++) {
+                const bool in_next = row0 + jj >= rows_owned;
+                tl[jj] = town[T * (in_next ? row0 + jj - rows_owned : 0) + t];
+                fl[jj] = in_next ? 1.0 : 0.0;
+            }
+        }
+        fft_forward<G>(v, my, t, tw, sync);
+        {
+            MagRegsD mr;
+            finish_mags_d(mr, mraw, t == 0);
+            spectral_apply<G>(v, t, mr, wn);
+        }
+        fft_inverse<G>(v, my, t, tw, sync);
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] = xl[jj];
+        if (any_next) {
+#pragma unroll
+            for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] += tl[jj] * fl[jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < SH; jj++) asm volatile("" : "+v"(xin[KEEP + jj]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            v2d* xo = xout_p + T * (g * SH);
+#pragma unroll
+            for (int j = 0; j < SH; j++) {
+                const v2d y = v[j] * wl[T * j];
+                xo[T * j + t] = (j < KEEP) ? acc[j] + y : y;
+            }
+            v2d nacc[KEEP];
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) {
+                const v2d y = v[j + SH] * wl[T * (j + SH)];
+                nacc[j] = (j + SH < KEEP) ? acc[j + SH] + y : y;
+            }
+#pragma unroll
+            for (int j = 0; j < KEEP; j++) acc[j] = nacc[j];
+            if (g == d.G - 1) {
+                if (d.has_next) {
+#pragma unroll
+                    for (int j = 0; j < KEEP; j++) tout[T * j + t] = acc[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KEEP; j++) xout_p[T * (rows_owned + j) + t] = acc[j];
+                }
+            }
+        }
+    }
+}
+template <int N> static constexpr size_t fused_d_lds_bytes() {
+    typedef Geo<N> G;
+    return ((size_t)(kFusedThreads / G::T) * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C) * 16 + (size_t)(kFusedThreads / G::T) * 4 + 16;
+}
+// out = x + tails, both fp64 (the fp64 fused path's last step)
+__global__ __launch_bounds__(256) void k_add_tails_d(const SegDesc* __restrict__ segs, const double* __restrict__ tail, double* __restrict__ out,
+                                                     int tail_len, int hop) {
+    const SegDesc d = segs[blockIdx.x];
+    if (!d.has_next) return;
+    double* o = out + d.s0 + (int64_t)d.G * hop;
+    const double* tp = tail + (int64_t)blockIdx.x * tail_len;
+    for (int i = threadIdx.x; i < tail_len; i += blockDim.x) o[i] += tp[i];
+}
+
 // out += tails (fp64), after k_finalize has converted the owned samples
 // (x and the tail are both fp32: the sum is formed in fp32 first when the output is fp32, exactly as the next iteration would
 // have read it, and in fp64 when the output is fp64)

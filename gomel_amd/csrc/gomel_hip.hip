@@ -477,6 +477,7 @@ struct gomel_batch {
     std::vector<SegDesc> segs;
     SegDesc* d_segs = nullptr;
     float* d_tail[2] = {nullptr, nullptr};  // [n_segs][N - hop]
+    double* d_taild[2] = {nullptr, nullptr}; // the same for the fp64 fused kernel
     int g_max = 0;
 };
 
@@ -484,7 +485,7 @@ static void batch_free(gomel_batch* b) {
     if (!b) return;
     DeviceGuard dg(b->h->device);
     void* ptrs[] = {b->d_spec, b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
-                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
+                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
@@ -579,6 +580,34 @@ template <int N> static void launch_fused_n(gomel_batch* b, int cur, int sh) {
         default: launch_fused_t<N, 8>(b, cur); break;
     }
 }
+template <int N, int SH> static hipError_t launch_fused_d_t(gomel_batch* b, int cur) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = kFusedThreads / G::T;
+    constexpr size_t lds = fused_d_lds_bytes<N>();
+    if (lds > 64 * 1024) {   // per device and cheap: set on every launch rather than remembered per process
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gl_fused_d<N, SH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int n = (int)b->segs.size();
+    hipLaunchKernelGGL((k_gl_fused_d<N, SH>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), lds, b->h->stream, b->d_xd[cur], b->d_taild[cur],
+                       b->d_xd[cur ^ 1], b->d_taild[cur ^ 1], b->d_segs, n, b->g_max, b->d_magd, b->d_nyqd, b->h->dt);
+    return hipSuccess;
+}
+template <int N> static hipError_t launch_fused_d_n(gomel_batch* b, int cur, int sh) {
+    switch (sh) {
+        case 1: return launch_fused_d_t<N, 1>(b, cur);
+        case 2: return launch_fused_d_t<N, 2>(b, cur);
+        case 4: return launch_fused_d_t<N, 4>(b, cur);
+        case 5: return launch_fused_d_t<N, 5>(b, cur);
+        default: return launch_fused_d_t<N, 8>(b, cur);
+    }
+}
+static hipError_t launch_fused_d(gomel_batch* b, int cur) {
+    const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
+    hipError_t e = hipSuccess;
+    GOMEL_DISPATCH_N(N, e = launch_fused_d_n<NN>(b, cur, sh));
+    return e;
+}
 static void launch_fused(gomel_batch* b, int cur) {
     const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
     GOMEL_DISPATCH_N(N, launch_fused_n<NN>(b, cur, sh));
@@ -623,8 +652,10 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
             const int64_t spb = h->generic ? 1 : 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
+            if (b->fast) HIPCHK(hipMemsetAsync(b->d_taild[0], 0, b->segs.size() * (size_t)(N - c.window) * 8, s));
             for (int it = 0; it < I; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
+                if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
                 if (h->generic)
                     hipLaunchKernelGGL(glany::k_any_frames<false>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
                                        b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, N, h->dt.windowd, h->dt.any);
@@ -638,6 +669,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
             HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
+            if (b->fast) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
         else if (b->io32) HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel32, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
@@ -925,7 +957,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // the chip (fused_min_frames); below that every frame in parallel (generic kernels) is faster.
     b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
     if (h->generic && (b->io32 || b->want_spec)) return GOMEL_ERR_UNSUPPORTED_N;
-    b->fast = (!b->precise && !b->want_spec && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;
+    b->fast = (!b->want_spec && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;   // (fused_applicable is false for generic lengths)
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
@@ -938,8 +970,18 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         alloc((void**)&b->d_nyqd, (size_t)b->total_frames * 8);
         alloc((void**)&b->d_xd[0], (size_t)b->total_len * 8);
         alloc((void**)&b->d_xd[1], (size_t)b->total_len * 8);
-        alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8);
-        alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+        if (b->fast) {   // fp64 fused kernel: segments and tails as in the fp32 case, no per-frame output buffer
+            plan_segments(b);
+            alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
+            alloc((void**)&b->d_taild[0], b->segs.size() * (size_t)(N - hop) * 8);
+            alloc((void**)&b->d_taild[1], b->segs.size() * (size_t)(N - hop) * 8);
+            if (!rc && hipMemcpy(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+            for (int i = 0; i < 2; i++)
+                if (!rc && hipMemset(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8) != hipSuccess) rc = GOMEL_ERR_HIP;
+        } else {
+            alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8);
+            alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+        }
     } else if (I > 0) {
         alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);
         alloc((void**)&b->d_nyq, ((size_t)b->total_frames + 4) * 4);   // + 4: lane t reads nyq[frame + (t & 3)] (load_mags_raw)

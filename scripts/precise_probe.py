@@ -1,19 +1,24 @@
+"""64-bit mode: fused fp64 kernel vs the generic fp64 kernels (same inputs), timing and agreement."""
 import os, sys, math, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import gomel_amd
-U, F, K, I = 256, 400, 192, 60
+geom = sys.argv[1] if len(sys.argv) > 1 else "T"
+G = {"T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096), "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),
+     "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048)}[geom]
+U, F, I = int(sys.argv[2]) if len(sys.argv) > 2 else 256, 400, int(sys.argv[3]) if len(sys.argv) > 3 else 60
+m = gomel_amd.NewMel()
+for k, v in dict(G, GriffinLimIterations=I).items(): setattr(m, k, v)
+e = m.engine(); e.set_precision(64)
+K = m.NumMels
 mels = [np.random.default_rng(u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
-seeds = [1000 + u for u in range(U)]
 res = {}
-for bits in (32, 64):
-    m = gomel_amd.NewMel(); m.MelFmax, m.Window, m.NumMels, m.Resolut, m.GriffinLimIterations = 16000, 1280, 192, 4096, I
-    e = m.engine(); e.set_precision(bits)
-    b = gomel_amd.Batch(e, [F * K] * U); b.upload(mels, None, seeds)
-    b.run(); b.sync()
-    tm = b.run_timed()
-    res[bits] = b.download(); b.close()
-    print(bits, "bits: %.1f ms per batch -> %.2f M frames/s" % (tm["total_ms"], U * F / tm["total_ms"] / 1e3))
-e = np.array([float(np.sqrt(np.mean((a - w) ** 2))) for a, w in zip(res[32], res[64])])
-print("fp32 vs fp64 kernels, 256 utterances: median %.2e p90 %.2e p99 %.2e max %.2e (# > 1e-4: %d)" % (np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max(), int((e > 1e-4).sum())))
+for path, name in ((1, "generic fp64"), (2, "fused fp64")):
+    e.set_path(path)
+    b = gomel_amd.Batch(e, [F * K] * U); b.upload(mels, None, list(range(U))); b.run(); b.sync()
+    t = time.perf_counter(); b.run(); b.sync(); dt = time.perf_counter() - t
+    tm = b.run_timed(); res[path] = b.download(); b.close()
+    print("%s %-13s: %.2f ms/step  %.3f M frames/s  dominant kernel %.4f ms/launch (fast_path %d)" % (geom, name, dt * 1e3, U * F / dt / 1e6, tm["dom_ms"] / max(1, tm["iter_launches"]), tm["fast_path"]))
+d = max(float(np.sqrt(np.mean((a - b) ** 2))) for a, b in zip(res[1], res[2]))
+print("max rms difference fused vs generic fp64 over %d utterances: %.2e" % (U, d))

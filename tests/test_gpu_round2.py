@@ -289,6 +289,37 @@ def test_many_mel_bands_and_corrupted_table_blob(oracle):
     assert ei.value.status == 10
 
 
+@pytest.mark.parametrize("N,K,fmax", [(4096, 192, 16000.0), (2048, 160, 8000.0), (1024, 80, 8000.0), (512, 40, 8000.0), (256, 24, 8000.0)])
+@pytest.mark.parametrize("SH", [1, 2, 4, 5, 8])
+def test_fused_fp64_kernel_matches_the_oracle(oracle, N, K, fmax, SH):
+    """64-bit mode through the fused fp64 kernel (forced: gomel_set_path 2) on every instantiation: ragged batch with segments of
+    every kind (single-segment utterances, first / middle / last segments, a one-frame utterance), 5 iterations, < 1e-9 from
+    the fp64 oracle; and bit-identical run to run."""
+    import gomel_amd
+    hop = SH * N // 16
+    fields = dict(NumMels=K, MelFmax=fmax, Window=hop, Resolut=N, GriffinLimIterations=5)
+    cfg = oracle.MelConfig(**fields)
+    m = mel_obj(fields)
+    e = m.engine()
+    e.set_precision(64)
+    e.set_path(2)
+    frames = [1, 2, 3, 17, 40, 66, 9] if N >= 2048 else [1, 2, 3, 17, 40, 150, 9]
+    mels = [oracle.random_logmel(f, K, seed=10 * SH + i) for i, f in enumerate(frames)]
+    seeds = list(range(len(mels)))
+    b = gomel_amd.Batch(e, [len(mm) for mm in mels])
+    b.upload(mels, None, seeds)
+    tm = b.run_timed()
+    got = b.download()
+    b.run()
+    again = b.download()
+    b.close()
+    assert tm["fast_path"] == 1
+    assert all(np.array_equal(a, c) for a, c in zip(got, again))
+    for mm, sd, g in zip(mels, seeds, got):
+        want = oracle.from_mel(cfg, mm.copy(), oracle.x0_splitmix(sd, len(g)))
+        assert rms(g - want) < 1e-9 * max(1.0, rms(want)), (N, SH, len(mm) // K, rms(g - want))
+
+
 def test_chunked_pipeline_on_a_ragged_batch(oracle):
     """gomel_from_mel_batch cuts big calls into chunks that cycle through three sets of device buffers (upload c+1 / compute c /
     download c-1): a ragged 300-utterance batch (3 ... 700 frames, 8+ chunks), explicit x0 for some utterances, against the same

@@ -3,6 +3,8 @@ import os, sys, math, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+from gomel_amd import _lib
+if os.environ.get("GOMEL_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["GOMEL_LIB"])   # A/B another build
 import gomel_amd
 geom = sys.argv[1] if len(sys.argv) > 1 else "T"
 G = {"T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096), "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),

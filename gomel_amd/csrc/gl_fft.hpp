@@ -112,7 +112,9 @@ template <bool INV, class V> GL_DEV void dft4_c(V& a0, V& a1, V& a2, V& a3) {
 #else
 #define GL_PKASM 0
 #endif
-#define GL_LEAD_NOP "s_nop 0\n\t"   // every block opens with one wait state (timing: free; it is not the bottleneck)
+#ifndef GL_LEAD_NOP
+#define GL_LEAD_NOP "s_nop 0\n\t"   // every block opens with one wait state (measured again in round 2)
+#endif
 
 // (a0, a1) <- (a0 * w0, a1 * w1), or * conj(w) when CONJ.  w may be VGPR pairs or (uniform constants) SGPR pairs.
 template <bool CONJ> GL_DEV void cmul2_asm(v2f& a0, v2f w0, v2f& a1, v2f w1) {

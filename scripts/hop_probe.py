@@ -1,0 +1,17 @@
+"""Throughput of the generic kernels (hops the fused kernel does not cover) next to the fused kernel at a nearby hop."""
+import os, sys, math, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import gomel_amd
+def run(N, hop, K, U=256, F=400, I=20):
+    m = gomel_amd.NewMel()
+    for k, v in dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=I).items(): setattr(m, k, v)
+    e = m.engine()
+    mels = [np.random.default_rng(u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
+    b = gomel_amd.Batch(e, [F * K] * U); b.upload(mels, None, list(range(U))); b.run(); b.sync()
+    t = time.perf_counter(); b.run(); b.sync(); dt = time.perf_counter() - t
+    tm = b.run_timed(); b.close(); e.close()
+    print("N %4d hop %4d: %.3f M frames/s (%d iterations)  path %s  dominant kernel %.4f ms/launch" % (N, hop, U * F / dt / 1e6 * I / 60.0 * 60 / I, I, "fused" if tm["fast_path"] else "generic", tm["dom_ms"] / tm["iter_launches"]))
+for N, hop, K in ((2048, 256, 80), (2048, 275, 80), (1024, 256, 80), (1024, 275, 80), (1024, 300, 80), (4096, 1280, 192), (4096, 1024, 192), (4096, 441, 192)):
+    run(N, hop, K)

@@ -370,9 +370,181 @@ GL_DEV v4f quad_from_rows(v2f r0, v2f r1, bool even) {
     return even ? v4f{r0.x, r0.y, n0.x, n0.y} : v4f{n1.x, n1.y, r1.x, r1.y};
 }
 
+// =============================================================================================== persistent small-batch path
+// k_gl_persist: ALL iterations of mel/mel.go:85-137 in ONE launch, for batches whose frames fit the chip at once (a single
+// utterance: 342 frames at the ToWavPng geometry).  One stream per frame as in k_gl_frames, but the stream keeps its frame for
+// the whole call: window, magnitudes and twiddle operands are loaded once, and per iteration the only memory traffic is the
+// frame's windowed output (16-B write-through stores into yw[it & 1]) and, next iteration, the gather of the overlap-add
+// x[n] = sum_k yw[k][n - k hop] from the up to 2*ceil(N/hop)-1 neighbouring frames -- in ascending frame order, so the sums are
+// the ones k_ola makes and the result is bit-identical to the k_gl_frames + k_ola pair.
+// Workgroups exchange INSIDE the launch (cdna_hip_programming.md Guideline 16, recipe R1): payload stored write-through (sc1),
+// every storing wave drains vmcnt, workgroup barrier, ONE lane stores the workgroup's flag = iteration + 1; a consumer polls its
+// neighbours' flags relaxed from one wave (one lane per neighbour workgroup), ONE agent-scope acquire, vmcnt(0), barrier, then
+// plain vector loads.  Two yw buffers suffice: a workgroup overwrites yw[it & 1] only after every neighbour has finished
+// iteration it - 1, i.e. has read the previous contents.  Every workgroup must be resident (the host checks the occupancy census
+// before choosing this path); spins are bounded by a wall-clock limit, a timeout sets *err and every workgroup leaves, and the
+// host then recomputes the batch with the per-iteration kernels.  flags[] and *err are zeroed by the host before every launch.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+constexpr int kPersistMaxNb = 15;            // neighbours on each side: (N-1)/hop <= 15, i.e. hop >= N/16
+constexpr unsigned kPersistSpinTicks = 20u * 100000u;   // default spin limit: 20 ms of the 100 MHz wall clock
+
 #ifdef GOMEL_STAMPS   // diagnostic build only (scripts/stamp_probe.py): per-phase cycle sums of k_gl_fused, all waves, all frames
 __device__ unsigned long long g_stamp_acc[21];
 #endif
+template <int N>
+__global__ __launch_bounds__(128, 1) void k_gl_persist(const float* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
+                                                      const float* __restrict__ mag, const float* __restrict__ nyq, float* yw0, float* yw1,
+                                                      unsigned int* flags, unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = 128 / T;
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;  // keeps the lanes in the barriers; nothing of it is stored
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    // every twiddle operand of this lane in registers for the whole call (the launch runs one wave per SIMD: 512 VGPRs): the
+    // acquire at the top of each iteration empties the L1, so table loads would go to the L2 every time
+    v2f w2r[16], w1r[16];
+#pragma unroll
+    for (int uu = 0; uu < G::NB2; uu++)
+#pragma unroll
+        for (int q = 0; q < G::R2; q++) w2r[uu * G::R2 + q] = tb.tw2[q * 8 + (t + T * uu) / G::R1];
+#pragma unroll
+    for (int uu = 0; uu < G::NB1; uu++)
+#pragma unroll
+        for (int q = 0; q < G::R1; q++) w1r[uu + G::NB1 * q] = tb.tw1[q * G::C1 + t + T * uu];
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, nullptr, w1r, 15, w2r};
+    auto sync = [] {
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    const UttDesc u = utts[frame_utt[frame]];
+    const int f = (int)(frame - u.fbase), F = u.frames;
+    const int nb = (N - 1) / hop;
+    // this frame's constants: window pairs, spectral-step operands, magnitudes
+    const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
+    v2f w[16], wn[8];
+#pragma unroll
+    for (int j = 0; j < 16; j++) w[j] = w2[t + T * j];
+    MagRaw mraw;
+    load_mags_raw<G>(mraw, t, mag + frame * G::C, nyq + frame);
+    load_wn<G>(wn, t, tb.wn);
+    MagRegs mr;
+    finish_mags(mr, mraw, t == 0);
+    // gather geometry.  Rows 2jp, 2jp+1 move as one 16-byte quad per lane (quad_from_rows): lane t holds the four samples from
+    // s = 2 (T (2jp + (t&1)) + (t & ~1)) of the frame.  With hop and N multiples of 4 all four have the same covering frames
+    // k0 .. k0 + cnt - 1, which depend on the frame only: computed once.
+    const bool even = !(t & 1);
+    const int lane_s = 2 * (T * (t & 1) + (t & ~1));
+    int k0[8], cnt[8], own[8];   // own[jp]: where this frame itself sits among the covering frames
+#pragma unroll
+    for (int jp = 0; jp < 8; jp++) {
+        const unsigned n = (unsigned)f * (unsigned)hop + (unsigned)(4 * T * jp + lane_s);   // < 2^31: the host admits short utterances only
+        const unsigned a = n >= (unsigned)N ? (n - (unsigned)N) / (unsigned)hop + 1u : 0u;
+        unsigned b = n / (unsigned)hop;
+        if (b > (unsigned)(F - 1)) b = (unsigned)(F - 1);
+        k0[jp] = (int)a; cnt[jp] = (int)(b - a + 1u); own[jp] = f - (int)a;
+    }
+    // the workgroups whose flags this one waits for: those holding frames f - nb .. f + nb of the utterance, over all its streams
+    int64_t need_lo = frame - (f < nb ? f : nb), need_hi = frame + ((F - 1 - f) < nb ? (F - 1 - f) : nb);
+    __shared__ long long need[2 * STREAMS];
+    __shared__ int gave_up;
+    if (t == 0) { need[2 * stream] = need_lo; need[2 * stream + 1] = need_hi; }
+    __syncthreads();
+    for (int s2 = 0; s2 < STREAMS; s2++) { need_lo = need[2 * s2] < need_lo ? need[2 * s2] : need_lo; need_hi = need[2 * s2 + 1] > need_hi ? need[2 * s2 + 1] : need_hi; }
+    const int wg_lo = (int)(need_lo / STREAMS), wg_n = (int)(need_hi / STREAMS) - wg_lo + 1;   // <= 2*15 + STREAMS + 1 <= 64 lanes
+    const __amdgpu_buffer_rsrc_t rs[2] = {__builtin_amdgcn_make_buffer_rsrc(yw0, 0, 0x7fffffff, 0x00020000),
+                                          __builtin_amdgcn_make_buffer_rsrc(yw1, 0, 0x7fffffff, 0x00020000)};
+    const unsigned my_off = (unsigned)(frame * N + lane_s) * 4u;   // byte offset of this lane's quad of row pair 0 (yw holds < 2^29 floats: host check)
+
+#ifdef GOMEL_STAMPS
+    Stamps st; st.start();
+#else
+    NoStamps st;
+#endif
+    v4f ownq[8];   // this frame's own windowed output of the previous iteration: its term of the overlap-add needs no load
+    for (int it = 0; it < iters; it++) {
+        v2f v[16];
+        if (it == 0) {
+            typedef v2f v2f_a4 __attribute__((aligned(4)));
+            const v2f_a4* xs = reinterpret_cast<const v2f_a4*>(x0 + u.xoff + (int64_t)f * hop);
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = xs[t + T * j];
+        } else {
+            st.mark(7);
+            if (threadIdx.x < 64) {   // wave 0 polls: lane l watches workgroup wg_lo + l, the last lane the timeout word
+                const int l = threadIdx.x;
+                const unsigned long long t0 = wall_clock64();
+                bool failed = false;
+                for (;;) {
+                    unsigned seen = l < wg_n ? __hip_atomic_load(flags + wg_lo + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    const unsigned e = l == 63 ? __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    if (__any(e != 0u)) { failed = true; break; }
+                    if (__all(seen >= (unsigned)it)) break;
+                    if (wall_clock64() - t0 > spin_ticks) { failed = true; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (l == 0) gave_up = failed ? 1 : 0;
+                st.mark(0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            st.mark(1);
+            if (gave_up) return;   // uniform over the workgroup: a neighbour never came (not resident / gave up): the host recomputes
+            const float* yp = (it & 1) ? yw0 : yw1;   // what iteration it - 1 stored
+            v4f acc[8];
+#pragma unroll
+            for (int jp = 0; jp < 8; jp++) acc[jp] = v4f{0.f, 0.f, 0.f, 0.f};
+            const float* base = yp + u.fbase * N + (int64_t)f * hop + lane_s;   // + 4 T jp + k (N - hop): frame k's copy of the sample
+            const int kstep = N - hop;
+            for (int dk = 0; dk <= nb; dk += 4) {   // cnt <= nb + 1; four frames' copies in flight per row pair (32 x 16 B per lane)
+                v4f a[8][4];
+#pragma unroll
+                for (int jp = 0; jp < 8; jp++) {
+                    const float* p = base + 4 * T * jp + (int64_t)(k0[jp] + dk) * kstep;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        a[jp][q] = dk + q == own[jp] ? ownq[jp] : dk + q < cnt[jp] ? *reinterpret_cast<const v4f*>(p + (int64_t)q * kstep) : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int jp = 0; jp < 8; jp++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[jp] += a[jp][q];
+            }
+#pragma unroll
+            for (int jp = 0; jp < 8; jp++) rows_from_quad(acc[jp], even, v[2 * jp], v[2 * jp + 1]);
+            st.mark(2);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] *= w[j];
+        fft_forward<G>(v, my, t, tw, sync);
+        st.mark(3);
+        spectral_apply<G>(v, t, mr, wn);
+        st.mark(4);
+        fft_inverse<G>(v, my, t, tw, sync);
+        st.mark(5);
+#pragma unroll
+        for (int jp = 0; jp < 8; jp++) ownq[jp] = quad_from_rows(v[2 * jp] * w[2 * jp], v[2 * jp + 1] * w[2 * jp + 1], even);
+        if (live) {
+#pragma unroll
+            for (int jp = 0; jp < 8; jp++)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, ownq[jp]), rs[it & 1], my_off + (unsigned)(4 * T * jp) * 4u, 0, 16);   // aux 16 = sc1
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the flag
+        st.mark(6);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef GOMEL_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int q = 0; q < 8; q++) atomicAdd(&g_stamp_acc[q], st.acc[q]);
+        atomicAdd(&g_stamp_acc[20], (unsigned long long)iters);
+    }
+#endif
+}
+
 
 template <int N, int SH>
 __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __restrict__ x_in, const float* __restrict__ tail_in,

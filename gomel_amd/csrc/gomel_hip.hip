@@ -109,6 +109,13 @@ struct gomel_handle {
     int precision = 32;           // 32: fp32 kernels (default); 64: fp64 generic kernels ("precise" mode)
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
     bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
+    // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
+    // slab of timeout words (one per live batch: the kernel's *err comes down with the waveforms, no extra round trip)
+    int persist_census = -1;      // workgroups of k_gl_persist<Resolut> the device holds at once (-1: not asked yet)
+    bool persist_off = false;     // a launch timed out once (another context held the CUs): per-iteration kernels from then on
+    unsigned* err_slab = nullptr; // [kErrSlots] pinned
+    std::vector<int> err_free;
+    unsigned persist_ticks = kPersistSpinTicks;   // spin limit in 100 MHz ticks (GOMEL_PERSIST_TICKS: the tests force a timeout with 0)
     std::vector<double> window;   // [N]
     std::vector<BinRow> undo;     // [N/2]
     std::vector<BinRow> dom;      // [K]
@@ -116,6 +123,8 @@ struct gomel_handle {
     DevPool pool;                 // working buffers of batches and of the one-shot entry points
     DevTables dt{};
 };
+
+constexpr int kErrSlots = 256;
 
 static double hz_to_mel(double v) { return 1127.0 * std::log(1.0 + (v / 700.0)); }  // mel/impl.go:304-308
 static double mel_to_hz(double v) { return 700.0 * (std::exp(v / 1127.0) - 1.0); }  // mel/impl.go:298-302
@@ -347,8 +356,13 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         if (h->copy_stream) hipStreamDestroy(h->copy_stream);
         delete h; return GOMEL_ERR_HIP;
     }
+    if (hipHostMalloc((void**)&h->err_slab, kErrSlots * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) {
+        memset(h->err_slab, 0, kErrSlots * sizeof(unsigned));
+        for (int i = kErrSlots - 1; i >= 0; i--) h->err_free.push_back(i);
+    } else { h->err_slab = nullptr; (void)hipGetLastError(); }   // no slab: the persistent path is simply never chosen
+    if (const char* e = getenv("GOMEL_PERSIST_TICKS")) h->persist_ticks = (unsigned)strtoul(e, nullptr, 10);
     rc = upload_tables(h);
-    if (rc) { hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); hipStreamDestroy(h->up_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
+    if (rc) { if (h->err_slab) hipHostFree(h->err_slab); hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); hipStreamDestroy(h->up_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
     *out = h;
     return GOMEL_OK;
 }
@@ -479,14 +493,23 @@ struct gomel_batch {
     float* d_tail[2] = {nullptr, nullptr};  // [n_segs][N - hop]
     double* d_taild[2] = {nullptr, nullptr}; // the same for the fp64 fused kernel
     int g_max = 0;
+    // persistent path (k_gl_persist): d_yw holds both ping-pong buffers, d_ctl = {err, pad[3], flags[n_wg]}
+    int persist = 0;
+    int n_wg = 0;
+    int err_slot = -1;
+    int32_t* d_frame_utt = nullptr;
+    unsigned* d_ctl = nullptr;
+    size_t ctl_bytes = 0;
 };
 
 static void batch_free(gomel_batch* b) {
     if (!b) return;
     DeviceGuard dg(b->h->device);
     void* ptrs[] = {b->d_spec, b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
-                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd};
+                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd,
+                    b->d_frame_utt, b->d_ctl};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
+    if (b->err_slot >= 0) b->h->err_free.push_back(b->err_slot);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
     delete b;
@@ -506,6 +529,25 @@ static int fused_shift(const gomel_config& c) {
     return (sh == 1 || sh == 2 || sh == 4 || sh == 5 || sh == 8) ? sh : 0;
 }
 static bool fused_applicable(const gomel_config& c) { return fused_shift(c) != 0; }
+
+// The persistent kernel (k_gl_persist) wants 16-byte quads that never straddle a hop (hop and N multiples of 4), at most
+// kPersistMaxNb neighbours on each side, and one of the register FFT cores.
+static bool persist_geometry_ok(const gomel_config& c) {
+    return gomel_supported_n(c.resolut) && c.window % 4 == 0 && c.window > 0 && (c.resolut - 1) / c.window <= kPersistMaxNb;
+}
+template <int N> static int persist_census_n(int device) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist<N>, 128, 0) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu * prop.multiProcessorCount;
+}
+static int persist_census(gomel_handle* h) {   // caller holds a DeviceGuard
+    if (h->persist_census < 0) { int n = 0; GOMEL_DISPATCH_N(h->cfg.resolut, n = persist_census_n<NN>(h->device)); h->persist_census = n; }
+    return h->persist_census;
+}
 
 // Batch size (total frames) from which the fused kernel beats the generic pair.  A fused stream walks at least gmin =
 // ceil((16-SH)/SH) frames one after the other, so a launch never takes less than gmin frame latencies, while the generic kernels
@@ -621,6 +663,26 @@ template <int N> static void launch_frames(gomel_batch* b, const float* x) {
                        b->total_frames, b->h->dt);
 }
 
+static int batch_run_impl(gomel_batch* b, gomel_timing* tm);
+
+// A persistent launch gave up (k_gl_persist: a workgroup waited 20 ms for a neighbour -- some other context held the CUs it
+// needed): nothing of its output is used.  x0 is still in d_x[0] (the kernel only reads it), so the batch is recomputed with the
+// per-iteration kernels, and the handle stops choosing the persistent path.  Caller holds h->mu and has synchronised the stream.
+static int persist_redo(gomel_batch* b, gomel_timing* tm) {
+    gomel_handle* h = b->h;
+    h->persist_off = true;
+    h->err_slab[b->err_slot] = 0;
+    b->persist = 0;
+    int rc = batch_run_impl(b, tm);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    return rc;
+}
+// after the stream has drained: did the batch's persistent launch complete?
+static int persist_verify(gomel_batch* b) {
+    if (!b->persist || !b->h->err_slab[b->err_slot]) return GOMEL_OK;
+    return persist_redo(b, nullptr);
+}
+
 static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     gomel_handle* h = b->h;
     const gomel_config& c = h->cfg;
@@ -680,7 +742,17 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         int cur = 0;
         const size_t tail_bytes = b->segs.size() * (size_t)(N - c.window) * 4;
         if (b->fast) HIPCHK(hipMemsetAsync(b->d_tail[0], 0, tail_bytes, s));  // x0 has no tail contributions
-        for (int it = 0; it < I; it++) {
+        if (b->persist) {   // all I iterations in one launch; x_I = overlap-add of the last iteration's frames
+            HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
+            if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
+            float* yw1 = b->d_yw + (size_t)b->total_frames * N;
+            GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist<NN>, dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, b->d_nyq,
+                                                   b->d_yw, yw1, b->d_ctl + 4, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->dt));
+            if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
+            hipLaunchKernelGGL(k_ola<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, ((I - 1) & 1) ? yw1 : b->d_yw, b->d_x[1], N, c.window);
+            cur = 1;
+        }
+        for (int it = 0; it < I && !b->persist; it++) {
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
             if (b->fast) launch_fused(b, cur);
             else { GOMEL_DISPATCH_N(N, launch_frames<NN>(b, b->d_x[cur])); }
@@ -704,20 +776,22 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         }
         }
     }
+    if (b->persist && I > 0) HIPCHK(hipMemcpyAsync(h->err_slab + b->err_slot, b->d_ctl, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
     if (tm) {
         HIPCHK(hipEventRecord(b->ev[3], s));
         HIPCHK(hipEventSynchronize(b->ev[3]));
+        if (b->persist && I > 0 && h->err_slab[b->err_slot]) return persist_redo(b, tm);
         HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
         HIPCHK(hipEventElapsedTime(&tm->iter_ms, b->ev[1], b->ev[2]));
         tm->dom_ms = 0.f;
-        for (int it = 0; it < I; it++) {
+        for (int it = 0; it < (b->persist ? std::min(I, 1) : I); it++) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, b->dom_ev[2 * it], b->dom_ev[2 * it + 1]));
             tm->dom_ms += ms;
         }
-        tm->iter_launches = I;
-        tm->fast_path = b->fast;
+        tm->iter_launches = b->persist ? std::min(I, 1) : I;
+        tm->fast_path = b->persist ? 2 : b->fast;
         tm->frames = b->total_frames;
     }
     return GOMEL_OK;
@@ -863,8 +937,9 @@ int gomel_get_window(const gomel_handle* h, double* w, size_t cap) {
 
 int gomel_set_path(gomel_handle* h, int mode) {
     if (!h) return GOMEL_ERR_NULL;
-    if (mode < 0 || mode > 2) return GOMEL_ERR_BAD_CONFIG;
+    if (mode < 0 || mode > 3) return GOMEL_ERR_BAD_CONFIG;
     if (mode == 2 && !fused_applicable(h->cfg)) return GOMEL_ERR_BAD_CONFIG;
+    if (mode == 3 && !persist_geometry_ok(h->cfg)) return GOMEL_ERR_BAD_CONFIG;
     std::lock_guard<std::mutex> lk(h->mu);
     h->path_mode = mode;
     return GOMEL_OK;
@@ -887,6 +962,7 @@ int gomel_destroy(gomel_handle* h) {
     if (h->up_stream) { hipStreamSynchronize(h->up_stream); hipStreamDestroy(h->up_stream); }
     h->pool.clear();
     if (h->d_blob) hipFree(h->d_blob);
+    if (h->err_slab) hipHostFree(h->err_slab);
     }
     delete h;
     return GOMEL_OK;
@@ -959,6 +1035,18 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     if (h->generic && (b->io32 || b->want_spec)) return GOMEL_ERR_UNSUPPORTED_N;
     b->fast = (!b->want_spec && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;   // (fused_applicable is false for generic lengths)
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
+    // ... and below the fused kernel's range, when every frame's stream fits the chip at once (one utterance, a few short ones),
+    // the persistent kernel runs all I iterations in one launch instead of 2 I.
+    if (!b->fast && !b->precise && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && I >= 2) {
+        const int spw = 128 / (N / 32);                                  // streams (frames) per workgroup
+        const int64_t n_wg = (b->total_frames + spw - 1) / spw;
+        if (!h->persist_off && h->err_slab && !h->err_free.empty() && n_wg <= persist_census(h) &&
+            b->total_frames * (int64_t)N < ((int64_t)1 << 28) && b->max_len < ((int64_t)1 << 30)) {
+            b->persist = 1; b->n_wg = (int)n_wg;
+            b->err_slot = h->err_free.back(); h->err_free.pop_back();
+        }
+    }
+    if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
     alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * (size_t)(N / 2 + 1) * 8 : (size_t)b->total_pairs * 2 * b->esz);
@@ -988,7 +1076,16 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
         alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
         if (!b->fast) alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
-        if (!b->fast) alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4);
+        if (!b->fast) alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4 * (b->persist ? 2 : 1));
+        if (b->persist) {
+            b->ctl_bytes = (16 + (size_t)b->n_wg * 4 + 15) & ~(size_t)15;
+            alloc((void**)&b->d_ctl, b->ctl_bytes);
+            alloc((void**)&b->d_frame_utt, (size_t)b->total_frames * 4);
+            std::vector<int32_t> fu((size_t)b->total_frames);
+            for (size_t u = 0; u < n_utt; u++)
+                for (int f = 0; f < b->utts[u].frames; f++) fu[(size_t)b->utts[u].fbase + f] = (int32_t)u;
+            if (!rc && hipMemcpy(b->d_frame_utt, fu.data(), fu.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+        }
         if (b->fast) {
             plan_segments(b);
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
@@ -1080,7 +1177,7 @@ int gomel_batch_sync(gomel_batch* b) {
     std::lock_guard<std::mutex> lk(b->h->mu);
     DeviceGuard dg(b->h->device); HIPCHK(dg.err);
     HIPCHK(hipStreamSynchronize(b->h->stream));
-    return GOMEL_OK;
+    return persist_verify(b);
 }
 
 static int batch_download_guarded(gomel_batch* b, void* const* out, const size_t* out_cap, int io32) {
@@ -1093,6 +1190,7 @@ static int batch_download_guarded(gomel_batch* b, void* const* out, const size_t
         if (!out[u]) return GOMEL_ERR_NULL;
         if (out_cap && out_cap[u] < (size_t)b->utts[u].len) return GOMEL_ERR_BUFFER_TOO_SMALL;
     }
+    if (b->persist) { HIPCHK(hipStreamSynchronize(h->stream)); int rv = persist_verify(b); if (rv) return rv; }
     PinnedScope pins;
     for (size_t u = 0; u < b->n_utt; u++) pins.want(out[u], (size_t)b->utts[u].len * b->esz);
     pins.commit(h->stream);
@@ -1205,6 +1303,7 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
             if (c + 1 < n_chunks) rc = upload(c + 1);                                   // queued before this chunk's kernels: runs beside them
             if (!rc && hipStreamWaitEvent(h->stream, up[c], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
             if (!rc) rc = batch_run_impl(b, nullptr);
+            if (!rc && b->persist) { if (hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP; else rc = persist_verify(b); }
             if (!rc && (hipEventRecord(done[c], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
             for (size_t u = 0; u < b->n_utt && !rc; u++)
                 if (hipMemcpyAsync(out[u0 + u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess)

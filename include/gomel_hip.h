@@ -72,7 +72,7 @@ typedef struct gomel_timing {
     float iter_ms;         /* the Griffin-Lim iteration launches only (sum over iterations)               */
     float dom_ms;          /* the dominant kernel alone, summed over its launches (events around each)    */
     int32_t iter_launches; /* number of dominant-kernel launches                                          */
-    int32_t fast_path;     /* 1 = fused sliding-window kernel, 0 = generic frames + overlap-add kernels   */
+    int32_t fast_path;     /* 0 = generic frames + overlap-add kernels, 1 = fused sliding-window kernel, 2 = persistent kernel */
     int64_t frames;        /* frames processed                                                            */
 } gomel_timing;
 
@@ -174,7 +174,13 @@ int gomel_batch_download_f32(gomel_batch* b, float* const* out, const size_t* ou
 int gomel_batch_destroy(gomel_batch* b);
 /* 0 = let the library choose (fused kernel when the hop allows it and the batch is big enough to fill the chip: from 1.5 k
  * frames at Resolut 4096 to 12 k at 256, measured crossovers);
- * 1 = force the generic kernels; 2 = require the fused kernel (error if the hop is not SH*Resolut/16, SH in 1,2,4,5,8) */
+ * persistent kernel -- every iteration in one launch -- when all frames of the batch fit the chip at once, i.e. one utterance
+ * or a few short ones, the hop is a multiple of 4 and at least Resolut/16; generic kernels otherwise);
+ * 1 = force the generic kernels; 2 = require the fused kernel (error if the hop is not SH*Resolut/16, SH in 1,2,4,5,8);
+ * 3 = require the persistent kernel (gomel_batch_create fails with GOMEL_ERR_BAD_CONFIG for a batch that does not fit it).
+ * The persistent kernel's workgroups wait for each other inside the launch: should another context keep them from all being
+ * resident, the launch gives up after 20 ms, the batch is recomputed with the generic kernels (same results, bit for bit) and
+ * the handle stops choosing that path. */
 int gomel_set_path(gomel_handle* h, int mode);
 /* Arithmetic of the Griffin-Lim iteration for batches created afterwards: 32 (default: fp32 kernels, the benchmarked path) or
  * 64 ("precise": the generic kernels in fp64 end to end, ~1e-12 from the fp64 reference arithmetic, several times slower). */

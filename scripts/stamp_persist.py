@@ -1,0 +1,32 @@
+"""Diagnostic: where an iteration's cycles go inside k_gl_persist.  Needs a -DGOMEL_STAMPS build:
+   hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DGOMEL_STAMPS -o abtest/lib_stamps.so gomel_amd/csrc/gomel_hip.hip
+usage: stamp_persist.py abtest/lib_stamps.so"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gomel_amd import _lib
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+import numpy as np
+import gomel_amd
+m = gomel_amd.NewMel()
+F, I = 342, 60
+for k, v in dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096, GriffinLimIterations=I).items(): setattr(m, k, v)
+e = m.engine()
+base = np.random.default_rng(0).uniform(np.log(1e-5), np.log(50.0), size=(F * m.NumMels, 2))
+b = gomel_amd.Batch(e, [F * m.NumMels]); b.upload([base], None, [0])
+L = _lib.lib()
+L.gomel_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+b.run(); b.sync()
+L.gomel_debug_stamps(None, 1)
+tm = b.run_timed()
+acc = (ctypes.c_ulonglong * 21)()
+L.gomel_debug_stamps(acc, 1)
+a = np.array(list(acc), dtype=np.float64)
+names = ["poll neighbours' flags (wave 0)", "acquire + vmcnt(0) + barrier", "gather: loads, sums, DPP", "window + forward FFT", "spectral step", "inverse FFT",
+         "window + 16-B sc1 stores + drain", "barrier + flag store (+ loop)"]
+tot = a[:8].sum(); wi = a[20]
+print(tm)
+print("ticks per wave-iteration: %.0f  (kernel %.3f us per iteration)" % (tot / wi, tm["dom_ms"] * 1e3 / I))
+for k in range(8):
+    print("  %-40s %7.0f  %5.1f %%" % (names[k], a[k] / wi, 100 * a[k] / tot))
+b.close()

@@ -1,0 +1,119 @@
+"""GPU tests of the persistent small-batch kernel (k_gl_persist: every Griffin-Lim iteration of mel/mel.go:85-137 in one launch,
+workgroups exchanging frames inside the launch).  Its overlap-add sums the frames in the order k_ola does, so the waveforms
+must equal the generic kernels' BIT FOR BIT -- any stale read of a neighbour's frame (the hazard of an in-launch exchange)
+shows up as a difference; parity with the oracle follows from the generic path's (tests/test_gpu_parity.py) and is checked
+directly on the ToWavPng geometry."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PERSIST, GENERIC = 3, 1
+
+
+def engine(N, hop, K, iters, path, fmax=8000.0):
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    m.NumMels, m.MelFmax, m.Window, m.Resolut, m.GriffinLimIterations = K, fmax, hop, N, iters
+    e = m.engine()
+    e.set_path(path)
+    return m, e
+
+
+def run(e, mels, seeds):
+    import gomel_amd
+    b = gomel_amd.Batch(e, [m.shape[0] for m in mels])
+    b.upload(mels, None, seeds)
+    tm = b.run_timed()
+    out = b.download()
+    b.close()
+    return out, tm
+
+
+def logmels(oracle, frames, K, seed0=0):
+    return [oracle.random_logmel(f, K, seed=seed0 + i) for i, f in enumerate(frames)]
+
+
+# hop = N/16 (15 neighbours each side), the fused kernel's shifts, hops that are no multiple of N/16, hop >= N (no overlap)
+GEOMETRIES = [(4096, 1280, 192), (4096, 256, 96), (4096, 1028, 96), (4096, 4096, 96), (4096, 5000, 96),
+              (2048, 256, 160), (2048, 128, 80), (2048, 516, 80),
+              (1024, 256, 80), (1024, 64, 80), (1024, 300, 80),
+              (512, 160, 64), (512, 32, 40), (512, 36, 40),
+              (256, 80, 40), (256, 16, 40), (256, 100, 40)]
+
+
+@pytest.mark.parametrize("N,hop,K", GEOMETRIES)
+def test_persistent_equals_generic_bit_for_bit(oracle, N, hop, K):
+    frames = [37, 1, 2, 9, 64]              # ragged batch: single-frame and two-frame utterances included
+    mels = logmels(oracle, frames, K)
+    seeds = list(range(len(frames)))
+    for iters in (2, 7):
+        mp, ep = engine(N, hop, K, iters, PERSIST)
+        outp, tmp = run(ep, mels, seeds)
+        mg, eg = engine(N, hop, K, iters, GENERIC)
+        outg, tmg = run(eg, mels, seeds)
+        assert tmp["fast_path"] == 2 and tmp["iter_launches"] == 1 and tmg["fast_path"] == 0
+        for a, b in zip(outp, outg):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        ep.close(); eg.close()
+
+
+def test_towavpng_single_utterance_uses_it_and_matches_the_oracle(oracle):
+    """BASELINE configs[1]: one 10 s utterance at 44.1 kHz, 342 frames, 60 iterations -- the library's own choice (path 0)."""
+    N, hop, K, F, I = 4096, 1280, 192, 342, 60
+    mel = oracle.random_logmel(F, K, seed=11)
+    m, e = engine(N, hop, K, I, 0, fmax=16000.0)
+    (out,), tm = run(e, [mel], [5])
+    assert tm["fast_path"] == 2 and tm["frames"] == F
+    mg, eg = engine(N, hop, K, I, GENERIC, fmax=16000.0)
+    (ref,), _ = run(eg, [mel], [5])
+    assert np.array_equal(out, ref)
+    cfg = oracle.MelConfig(NumMels=K, MelFmax=16000.0, Window=hop, Resolut=N, GriffinLimIterations=5)
+    m5, e5 = engine(N, hop, K, 5, 0, fmax=16000.0)
+    (out5,), tm5 = run(e5, [mel], [5])
+    assert tm5["fast_path"] == 2
+    want = oracle.from_mel(cfg, mel.copy(), oracle.x0_splitmix(5, len(out5)))
+    assert float(np.sqrt(np.mean((out5 - want) ** 2))) < 1e-4
+    # the host-to-host entry points take the same path
+    assert np.array_equal(np.asarray(m.FromMel(mel.copy(), seed=5)), ref)
+    for x in (e, eg, e5):
+        x.close()
+
+
+def test_batches_beyond_the_chip_fall_to_the_other_kernels(oracle):
+    import gomel_amd
+    m, e = engine(4096, 1280, 192, 3, 0, fmax=16000.0)
+    for n_utt, frames, want in ((1, 300, 2), (1, 512, 2), (2, 300, 0), (8, 300, 1)):
+        b = gomel_amd.Batch(e, [frames * 192] * n_utt)
+        b.upload(logmels(oracle, [frames] * n_utt, 192), None, list(range(n_utt)))
+        assert b.run_timed()["fast_path"] == want, (n_utt, frames)
+        b.close()
+    e.set_path(PERSIST)
+    with pytest.raises(gomel_amd.GomelError):
+        gomel_amd.Batch(e, [600 * 192])           # required, but 600 frames do not fit the chip at once
+    e.close()
+
+
+def test_timeout_recomputes_with_the_generic_kernels(oracle, monkeypatch):
+    """GOMEL_PERSIST_TICKS=0: every wait that is not satisfied at its first poll gives up -- what happens when another context
+    keeps the workgroups from being resident together.  The batch must come back right, and the handle must stop choosing the path."""
+    N, hop, K, F, I = 4096, 1280, 192, 342, 8
+    mel = oracle.random_logmel(F, K, seed=3)
+    mg, eg = engine(N, hop, K, I, GENERIC, fmax=16000.0)
+    (ref,), _ = run(eg, [mel], [9])
+    monkeypatch.setenv("GOMEL_PERSIST_TICKS", "0")
+    m, e = engine(N, hop, K, I, 0, fmax=16000.0)
+    monkeypatch.delenv("GOMEL_PERSIST_TICKS")
+    import gomel_amd
+    b = gomel_amd.Batch(e, [F * K])
+    b.upload([mel], None, [9])
+    b.run()
+    out = b.download()[0]
+    b.close()
+    assert np.array_equal(out, ref)
+    (out2,), tm2 = run(e, [mel], [9])
+    assert np.array_equal(out2, ref)
+    assert tm2["fast_path"] in (0, 2)       # 0 once a wait has really timed out; 2 if every poll happened to hit first time
+    e.close(); eg.close()

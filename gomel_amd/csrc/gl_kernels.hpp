@@ -308,6 +308,37 @@ __global__ __launch_bounds__(128) void k_gl_frames_d(const double* __restrict__ 
     }
 }
 
+// the same sum written straight to the caller's precision: overlap-add + mel/mel.go:138 after the persistent kernel's last iteration
+template <class OutT>
+__global__ __launch_bounds__(256) void k_ola_out(const UttDesc* __restrict__ utts, int n_utt, const float* __restrict__ yw, OutT* __restrict__ out, int N, int hop) {
+    for (int iu = blockIdx.y; iu < n_utt; iu += gridDim.y) {
+        const UttDesc u = utts[iu];
+        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
+            int64_t k0 = n >= N ? (n - N) / hop + 1 : 0;
+            int64_t k1 = n / hop;
+            if (k1 > u.frames - 1) k1 = u.frames - 1;
+            float acc = 0;
+            for (int64_t k = k0; k <= k1; k++) acc += yw[(u.fbase + k) * N + (n - k * hop)];
+            out[u.xoff + n] = (OutT)acc;
+        }
+    }
+}
+
+// per-frame index tables of a batch from its utterance descriptors: where the frame starts in the signal buffers, whose it is
+__global__ __launch_bounds__(256) void k_frame_index(const UttDesc* __restrict__ utts, int n_utt, int64_t n_frames, int hop, int64_t* __restrict__ frame_xoff,
+                                                     int32_t* __restrict__ frame_utt) {
+    const int64_t fr = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (fr >= n_frames) return;
+    int lo = 0, hi = n_utt - 1;   // the last utterance whose first frame is <= fr
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (utts[mid].fbase <= fr) lo = mid; else hi = mid - 1;
+    }
+    const UttDesc u = utts[lo];
+    if (frame_xoff) frame_xoff[fr] = u.xoff + (fr - u.fbase) * hop;
+    if (frame_utt) frame_utt[fr] = lo;
+}
+
 // x'[n] = sum over the frames covering n of yw[k][n - k*hop], in frame order (mel/mel.go:115-125).
 template <class S>
 __global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, int n_utt, const S* __restrict__ yw, S* __restrict__ xn,
@@ -374,27 +405,44 @@ GL_DEV v4f quad_from_rows(v2f r0, v2f r1, bool even) {
 // k_gl_persist: ALL iterations of mel/mel.go:85-137 in ONE launch, for batches whose frames fit the chip at once (a single
 // utterance: 342 frames at the ToWavPng geometry).  One stream per frame as in k_gl_frames, but the stream keeps its frame for
 // the whole call: window, magnitudes and twiddle operands are loaded once, and per iteration the only memory traffic is the
-// frame's windowed output (16-B write-through stores into yw[it & 1]) and, next iteration, the gather of the overlap-add
+// frame's windowed output y (16-B write-through stores) and, next iteration, the gather of the overlap-add
 // x[n] = sum_k yw[k][n - k hop] from the up to 2*ceil(N/hop)-1 neighbouring frames -- in ascending frame order, so the sums are
 // the ones k_ola makes and the result is bit-identical to the k_gl_frames + k_ola pair.
-// Workgroups exchange INSIDE the launch (cdna_hip_programming.md Guideline 16, recipe R1): payload stored write-through (sc1),
-// every storing wave drains vmcnt, workgroup barrier, ONE lane stores the workgroup's flag = iteration + 1; a consumer polls its
-// neighbours' flags relaxed from one wave (one lane per neighbour workgroup), ONE agent-scope acquire, vmcnt(0), barrier, then
-// plain vector loads.  Two yw buffers suffice: a workgroup overwrites yw[it & 1] only after every neighbour has finished
-// iteration it - 1, i.e. has read the previous contents.  Every workgroup must be resident (the host checks the occupancy census
-// before choosing this path); spins are bounded by a wall-clock limit, a timeout sets *err and every workgroup leaves, and the
-// host then recomputes the batch with the per-iteration kernels.  flags[] and *err are zeroed by the host before every launch.
+//
+// The exchange between frames is the critical path (a frame cannot start iteration i+1 before its neighbours finished i), so it
+// carries no flag, no drain-then-signal and no fence: THE DATA IS THE SIGNAL (cdna_hip_programming.md Guideline 16, form R2,
+// with a sentinel instead of a tag).  y lives in THREE buffers, iteration i writes buf[i % 3].  A slot a reader may look at holds
+// either the sentinel (all-ones words, a NaN no arithmetic produces) or the fresh value, never an older y:
+//   * stream P, iteration i, right after its gather: stores the sentinel over its own slot of buf[(i+1) % 3].  That slot held
+//     y_P(i-2); its readers were the neighbours' gathers of iteration i-1, which are over, because P has just consumed what those
+//     neighbours produced AFTER them (their y(i-1)).
+//   * P then computes (two FFTs), executes s_waitcnt vmcnt(0) -- free by then, and it orders the sentinel before everything
+//     that follows -- and stores y_P(i) into buf[i % 3] (which holds the sentinel P wrote one iteration earlier).
+//   * a reader in iteration i+1 loads the quads it needs from buf[i % 3] with sc1 loads (agent-coherent: they do not hit a stale
+//     L1 line) and re-loads those that still show the sentinel in ANY of their four words, so a torn 16-byte read cannot pass.
+//     It cannot see y_P(i-3) there: it has consumed y_P(i-1) already, and P drained the sentinel that replaced y_P(i-3) before
+//     storing y_P(i-1).
+// The host fills all three buffers with the sentinel before every launch.  Every stream must be resident (the host checks the
+// occupancy census before choosing this path); the re-load loop is bounded by a wall-clock limit, a timeout -- neighbours not
+// resident, or data that really contains the sentinel pattern -- sets *err, after which every stream runs through without
+// waiting, and the host recomputes the batch with the per-iteration kernels.
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 constexpr int kPersistMaxNb = 15;            // neighbours on each side: (N-1)/hop <= 15, i.e. hop >= N/16
 constexpr unsigned kPersistSpinTicks = 20u * 100000u;   // default spin limit: 20 ms of the 100 MHz wall clock
+constexpr unsigned kPersistSentinel = 0xffffffffu;
 
-#ifdef GOMEL_STAMPS   // diagnostic build only (scripts/stamp_probe.py): per-phase cycle sums of k_gl_fused, all waves, all frames
+GL_DEV bool persist_fresh(v4u q) { return q.x != kPersistSentinel && q.y != kPersistSentinel && q.z != kPersistSentinel && q.w != kPersistSentinel; }
+
+#ifdef GOMEL_STAMPS   // diagnostic build only (scripts/stamp_probe.py, stamp_persist.py): per-phase cycle sums, all waves
 __device__ unsigned long long g_stamp_acc[21];
 #endif
-template <int N>
-__global__ __launch_bounds__(128, 1) void k_gl_persist(const float* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
-                                                      const float* __restrict__ mag, const float* __restrict__ nyq, float* yw0, float* yw1,
-                                                      unsigned int* flags, unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, DevTables tb) {
+// OCC = waves per SIMD the kernel is built for: 1 = everything in registers (512 VGPRs: twiddles, window, four covering frames'
+// quads in flight), 2 = twice the resident streams (256 VGPRs: twiddles and window re-read through the L1, which nothing
+// invalidates here; two covering frames in flight).
+template <int N, int OCC>
+__global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
+                                                      const float* __restrict__ mag, const float* __restrict__ nyq, float* yw,
+                                                      unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb) {
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = 128 / T;
     __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
@@ -403,18 +451,20 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist(const float* __restrict__
     const bool live = frame < n_frames;
     if (!live) frame = n_frames - 1;  // keeps the lanes in the barriers; nothing of it is stored
     v2f* my = lds + stream * G::LDS_SLOTS;
-    // every twiddle operand of this lane in registers for the whole call (the launch runs one wave per SIMD: 512 VGPRs): the
-    // acquire at the top of each iteration empties the L1, so table loads would go to the L2 every time
+    // every twiddle operand of this lane in registers for the whole call (the launch runs one wave per SIMD: 512 VGPRs)
     v2f w2r[16], w1r[16];
+    if constexpr (OCC == 1) {
 #pragma unroll
-    for (int uu = 0; uu < G::NB2; uu++)
+        for (int uu = 0; uu < G::NB2; uu++)
 #pragma unroll
-        for (int q = 0; q < G::R2; q++) w2r[uu * G::R2 + q] = tb.tw2[q * 8 + (t + T * uu) / G::R1];
+            for (int q = 0; q < G::R2; q++) w2r[uu * G::R2 + q] = tb.tw2[q * 8 + (t + T * uu) / G::R1];
 #pragma unroll
-    for (int uu = 0; uu < G::NB1; uu++)
+        for (int uu = 0; uu < G::NB1; uu++)
 #pragma unroll
-        for (int q = 0; q < G::R1; q++) w1r[uu + G::NB1 * q] = tb.tw1[q * G::C1 + t + T * uu];
-    const Twiddles<v2f> tw{tb.tw1, tb.tw2, nullptr, w1r, 15, w2r};
+            for (int q = 0; q < G::R1; q++) w1r[uu + G::NB1 * q] = tb.tw1[q * G::C1 + t + T * uu];
+    }
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, nullptr, OCC == 1 ? w1r : nullptr, OCC == 1 ? 15 : 0, OCC == 1 ? w2r : nullptr};
+    constexpr int DEPTH = OCC == 1 ? 4 : 2;   // covering frames in flight per row pair
     auto sync = [] {
         if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -425,47 +475,54 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist(const float* __restrict__
     // this frame's constants: window pairs, spectral-step operands, magnitudes
     const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
     v2f w[16], wn[8];
+    if constexpr (OCC == 1) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) w[j] = w2[t + T * j];
+        for (int j = 0; j < 16; j++) w[j] = w2[t + T * j];
+    }
     MagRaw mraw;
-    load_mags_raw<G>(mraw, t, mag + frame * G::C, nyq + frame);
-    load_wn<G>(wn, t, tb.wn);
     MagRegs mr;
-    finish_mags(mr, mraw, t == 0);
+    if constexpr (OCC == 1) {
+        load_mags_raw<G>(mraw, t, mag + frame * G::C, nyq + frame);
+        load_wn<G>(wn, t, tb.wn);
+        finish_mags(mr, mraw, t == 0);
+    }
     // gather geometry.  Rows 2jp, 2jp+1 move as one 16-byte quad per lane (quad_from_rows): lane t holds the four samples from
     // s = 2 (T (2jp + (t&1)) + (t & ~1)) of the frame.  With hop and N multiples of 4 all four have the same covering frames
     // k0 .. k0 + cnt - 1, which depend on the frame only: computed once.
     const bool even = !(t & 1);
     const int lane_s = 2 * (T * (t & 1) + (t & ~1));
-    int k0[8], cnt[8], own[8];   // own[jp]: where this frame itself sits among the covering frames
+    int geo[8];   // k0 | cnt << 20 | own << 25, own = where this frame itself sits among the covering frames (frames per utterance < 2^20: host check)
 #pragma unroll
     for (int jp = 0; jp < 8; jp++) {
         const unsigned n = (unsigned)f * (unsigned)hop + (unsigned)(4 * T * jp + lane_s);   // < 2^31: the host admits short utterances only
         const unsigned a = n >= (unsigned)N ? (n - (unsigned)N) / (unsigned)hop + 1u : 0u;
         unsigned b = n / (unsigned)hop;
         if (b > (unsigned)(F - 1)) b = (unsigned)(F - 1);
-        k0[jp] = (int)a; cnt[jp] = (int)(b - a + 1u); own[jp] = f - (int)a;
+        geo[jp] = (int)(a | (b - a + 1u) << 20 | ((unsigned)f - a) << 25);
     }
-    // the workgroups whose flags this one waits for: those holding frames f - nb .. f + nb of the utterance, over all its streams
-    int64_t need_lo = frame - (f < nb ? f : nb), need_hi = frame + ((F - 1 - f) < nb ? (F - 1 - f) : nb);
-    __shared__ long long need[2 * STREAMS];
-    __shared__ int gave_up;
-    if (t == 0) { need[2 * stream] = need_lo; need[2 * stream + 1] = need_hi; }
-    __syncthreads();
-    for (int s2 = 0; s2 < STREAMS; s2++) { need_lo = need[2 * s2] < need_lo ? need[2 * s2] : need_lo; need_hi = need[2 * s2 + 1] > need_hi ? need[2 * s2 + 1] : need_hi; }
-    const int wg_lo = (int)(need_lo / STREAMS), wg_n = (int)(need_hi / STREAMS) - wg_lo + 1;   // <= 2*15 + STREAMS + 1 <= 64 lanes
-    const __amdgpu_buffer_rsrc_t rs[2] = {__builtin_amdgcn_make_buffer_rsrc(yw0, 0, 0x7fffffff, 0x00020000),
-                                          __builtin_amdgcn_make_buffer_rsrc(yw1, 0, 0x7fffffff, 0x00020000)};
-    const unsigned my_off = (unsigned)(frame * N + lane_s) * 4u;   // byte offset of this lane's quad of row pair 0 (yw holds < 2^29 floats: host check)
-
+    // yw = the three buffers back to back, [3][n_frames][N] floats (< 2^32 bytes: host check); one descriptor, the buffer chosen by
+    // the scalar offset operand
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(yw, 0, 0xffffffff, 0x00020000);
+    const unsigned buf_bytes = (unsigned)(n_frames * N) * 4u;
+    const unsigned my_off = (unsigned)(frame * N + lane_s) * 4u;   // byte offset of this lane's quad of row pair 0 (a buffer holds < 2^28 floats: host check)
+    // byte offset of frame k0's copy of this lane's quad of row pair 0; + 4 T jp floats per row pair, + (N - hop) floats per covering frame
+    const unsigned base_off = (unsigned)(u.fbase * N + (int64_t)f * hop + lane_s) * 4u;
+    const unsigned kstep = (unsigned)(N - hop) * 4u;
+    const v4u sentinel = v4u{kPersistSentinel, kPersistSentinel, kPersistSentinel, kPersistSentinel};
+    bool dead = false;   // a wait timed out somewhere (here or, seen through *err, elsewhere): no more waiting, the host recomputes
 #ifdef GOMEL_STAMPS
     Stamps st; st.start();
 #else
     NoStamps st;
 #endif
     v4f ownq[8];   // this frame's own windowed output of the previous iteration: its term of the overlap-add needs no load
+    int cur = 0, prev = 2, next = 1;   // it % 3, (it - 1) % 3, (it + 1) % 3
     for (int it = 0; it < iters; it++) {
         v2f v[16];
+        // OCC 2: the table addresses of an iteration (window, twiddles, magnitudes: some 40 64-bit pointers) are loop invariants the
+        // compiler would hoist and then spill; an opaque copy of the lane index makes it rebuild them where they are used
+        int tl = t;
+        if constexpr (OCC != 1) asm volatile("" : "+v"(tl));
         if (it == 0) {
             typedef v2f v2f_a4 __attribute__((aligned(4)));
             const v2f_a4* xs = reinterpret_cast<const v2f_a4*>(x0 + u.xoff + (int64_t)f * hop);
@@ -473,69 +530,113 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist(const float* __restrict__
             for (int j = 0; j < 16; j++) v[j] = xs[t + T * j];
         } else {
             st.mark(7);
-            if (threadIdx.x < 64) {   // wave 0 polls: lane l watches workgroup wg_lo + l, the last lane the timeout word
-                const int l = threadIdx.x;
-                const unsigned long long t0 = wall_clock64();
-                bool failed = false;
-                for (;;) {
-                    unsigned seen = l < wg_n ? __hip_atomic_load(flags + wg_lo + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                    const unsigned e = l == 63 ? __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                    if (__any(e != 0u)) { failed = true; break; }
-                    if (__all(seen >= (unsigned)it)) break;
-                    if (wall_clock64() - t0 > spin_ticks) { failed = true; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (l == 0) gave_up = failed ? 1 : 0;
-                st.mark(0);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            st.mark(1);
-            if (gave_up) return;   // uniform over the workgroup: a neighbour never came (not resident / gave up): the host recomputes
-            const float* yp = (it & 1) ? yw0 : yw1;   // what iteration it - 1 stored
             v4f acc[8];
 #pragma unroll
             for (int jp = 0; jp < 8; jp++) acc[jp] = v4f{0.f, 0.f, 0.f, 0.f};
-            const float* base = yp + u.fbase * N + (int64_t)f * hop + lane_s;   // + 4 T jp + k (N - hop): frame k's copy of the sample
-            const int kstep = N - hop;
-            for (int dk = 0; dk <= nb; dk += 4) {   // cnt <= nb + 1; four frames' copies in flight per row pair (32 x 16 B per lane)
-                v4f a[8][4];
+            for (int dk = 0; dk <= nb; dk += DEPTH) {   // cnt <= nb + 1; DEPTH frames' copies in flight per row pair (up to 32 x 16 B per lane)
+                v4u a[8][DEPTH];
+                unsigned todo = 0;   // bit 4 jp + q: the quad is a neighbour's and not in yet
 #pragma unroll
-                for (int jp = 0; jp < 8; jp++) {
-                    const float* p = base + 4 * T * jp + (int64_t)(k0[jp] + dk) * kstep;
+                for (int jp = 0; jp < 8; jp++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        a[jp][q] = dk + q == own[jp] ? ownq[jp] : dk + q < cnt[jp] ? *reinterpret_cast<const v4f*>(p + (int64_t)q * kstep) : v4f{0.f, 0.f, 0.f, 0.f};
+                    for (int q = 0; q < DEPTH; q++) {
+                        a[jp][q] = v4u{0u, 0u, 0u, 0u};
+                        if (dk + q < (geo[jp] >> 20 & 31) && (OCC != 1 || dk + q != (geo[jp] >> 25 & 31))) todo |= 1u << (DEPTH * jp + q);
+                    }
+                if (dead) todo = 0;
+                unsigned long long t0 = 0;
+                for (unsigned spins = 0;; spins++) {
+#pragma unroll
+                    for (int jp = 0; jp < 8; jp++)
+#pragma unroll
+                        for (int q = 0; q < DEPTH; q++)
+                            if (todo & (1u << (DEPTH * jp + q)))
+                                a[jp][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(4 * T * jp) * 4u + (unsigned)((geo[jp] & 0xfffff) + dk + q) * kstep, (unsigned)prev * buf_bytes, 16);   // aux 16 = sc1
+#pragma unroll
+                    for (int jp = 0; jp < 8; jp++)
+#pragma unroll
+                        for (int q = 0; q < DEPTH; q++)
+                            if ((todo & (1u << (DEPTH * jp + q))) && persist_fresh(a[jp][q])) todo &= ~(1u << (DEPTH * jp + q));
+#ifdef GOMEL_STAMPS
+                    st.acc[2] += 1;   // load rounds
+#endif
+                    if (!__any(todo != 0u)) break;
+                    // some neighbour has not stored yet: look again, but not for ever
+                    // (the re-load goes out at once: a look at *err costs a round trip of its own, so only every 16th time)
+                    if (t0 == 0) t0 = wall_clock64();
+                    const bool other = (spins & 15u) == 15u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                    if (other || wall_clock64() - t0 > spin_ticks) {
+                        if (!other && (threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                    for (int d = 0; d < retry_nap; d++) __builtin_amdgcn_s_sleep(1);   // re-loads at full rate slow the stores they are waiting for
                 }
 #pragma unroll
                 for (int jp = 0; jp < 8; jp++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc[jp] += a[jp][q];
+                    for (int q = 0; q < DEPTH; q++) acc[jp] += (OCC == 1 && dk + q == (geo[jp] >> 25 & 31)) ? ownq[jp] : __builtin_bit_cast(v4f, a[jp][q]);   // absent frames add the zeros a[][] started as
             }
+            st.mark(0);
+#ifdef GOMEL_STAMPS_RELOAD   // diagnostic: the same loads once more, nobody writing: the bare round trip
+            {
+                v4u r[8][4];
+#pragma unroll
+                for (int jp = 0; jp < 8; jp++)
+#pragma unroll
+                    for (int q = 0; q < DEPTH; q++)
+                        if (q < (geo[jp] >> 20 & 31) && q != (geo[jp] >> 25 & 31)) r[jp][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(4 * T * jp) * 4u + (unsigned)((geo[jp] & 0xfffff) + q) * kstep, (unsigned)prev * buf_bytes, 16);
+                        else r[jp][q] = v4u{0u, 0u, 0u, 0u};
+                unsigned x_ = 0;
+#pragma unroll
+                for (int jp = 0; jp < 8; jp++)
+#pragma unroll
+                    for (int q = 0; q < DEPTH; q++) x_ |= r[jp][q].x;
+                asm volatile("" :: "v"(x_));
+                st.mark(7);
+            }
+#endif
 #pragma unroll
             for (int jp = 0; jp < 8; jp++) rows_from_quad(acc[jp], even, v[2 * jp], v[2 * jp + 1]);
-            st.mark(2);
+        }
+        // the slot iteration it + 1 will fill: nobody reads y(it - 2) any more (see above).  Early, so that the drain below is free.
+        if (live) {
+#pragma unroll
+            for (int jp = 0; jp < 8; jp++) __builtin_amdgcn_raw_buffer_store_b128(sentinel, rs, my_off + (unsigned)(4 * T * jp) * 4u, (unsigned)next * buf_bytes, 16);
+        }
+        st.mark(1);
+        if constexpr (OCC != 1) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) w[j] = w2[tl + T * j];
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= w[j];
-        fft_forward<G>(v, my, t, tw, sync);
+        if constexpr (OCC != 1) {   // the spectral step's operands: issued here, needed a forward FFT later
+            load_mags_raw<G>(mraw, tl, mag + frame * G::C, nyq + frame);
+            load_wn<G>(wn, tl, tb.wn);
+        }
+        fft_forward<G>(v, my, tl, tw, sync);
         st.mark(3);
+        if constexpr (OCC != 1) finish_mags(mr, mraw, t == 0);
         spectral_apply<G>(v, t, mr, wn);
         st.mark(4);
-        fft_inverse<G>(v, my, t, tw, sync);
+        if constexpr (OCC != 1) asm volatile("" : "+v"(tl));
+        fft_inverse<G>(v, my, tl, tw, sync);
         st.mark(5);
+        if constexpr (OCC != 1) {
+            asm volatile("" : "+v"(tl));
 #pragma unroll
-        for (int jp = 0; jp < 8; jp++) ownq[jp] = quad_from_rows(v[2 * jp] * w[2 * jp], v[2 * jp + 1] * w[2 * jp + 1], even);
-        if (live) {
-#pragma unroll
-            for (int jp = 0; jp < 8; jp++)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, ownq[jp]), rs[it & 1], my_off + (unsigned)(4 * T * jp) * 4u, 0, 16);   // aux 16 = sc1
+            for (int j = 0; j < 16; j++) w[j] = w2[tl + T * j];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sentinel stores above are through: fresh data can never be overtaken by them
+#pragma unroll
+        for (int jp = 0; jp < 8; jp++) {
+            const v4f q = quad_from_rows(v[2 * jp] * w[2 * jp], v[2 * jp + 1] * w[2 * jp + 1], even);
+            if constexpr (OCC == 1) ownq[jp] = q;
+            if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q), rs, my_off + (unsigned)(4 * T * jp) * 4u, (unsigned)cur * buf_bytes, 16);   // aux 16 = sc1
+        }
         st.mark(6);
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prev = cur; cur = next; next = next == 2 ? 0 : next + 1;
     }
 #ifdef GOMEL_STAMPS
     if ((threadIdx.x & 63) == 0) {
@@ -544,7 +645,6 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist(const float* __restrict__
     }
 #endif
 }
-
 
 template <int N, int SH>
 __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __restrict__ x_in, const float* __restrict__ tail_in,

@@ -111,10 +111,11 @@ struct gomel_handle {
     bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
     // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
     // slab of timeout words (one per live batch: the kernel's *err comes down with the waveforms, no extra round trip)
-    int persist_census = -1;      // workgroups of k_gl_persist<Resolut> the device holds at once (-1: not asked yet)
+    int persist_census[2] = {-1, -1};   // workgroups of k_gl_persist<Resolut, 1 | 2> the device holds at once (-1: not asked yet)
     bool persist_off = false;     // a launch timed out once (another context held the CUs): per-iteration kernels from then on
     unsigned* err_slab = nullptr; // [kErrSlots] pinned
     std::vector<int> err_free;
+    int persist_nap = 2;          // s_sleep(1) units between two looks at a slot that still shows the sentinel (GOMEL_PERSIST_NAP)
     unsigned persist_ticks = kPersistSpinTicks;   // spin limit in 100 MHz ticks (GOMEL_PERSIST_TICKS: the tests force a timeout with 0)
     std::vector<double> window;   // [N]
     std::vector<BinRow> undo;     // [N/2]
@@ -361,6 +362,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         for (int i = kErrSlots - 1; i >= 0; i--) h->err_free.push_back(i);
     } else { h->err_slab = nullptr; (void)hipGetLastError(); }   // no slab: the persistent path is simply never chosen
     if (const char* e = getenv("GOMEL_PERSIST_TICKS")) h->persist_ticks = (unsigned)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("GOMEL_PERSIST_NAP")) h->persist_nap = atoi(e);
     rc = upload_tables(h);
     if (rc) { if (h->err_slab) hipHostFree(h->err_slab); hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); hipStreamDestroy(h->up_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
     *out = h;
@@ -493,7 +495,7 @@ struct gomel_batch {
     float* d_tail[2] = {nullptr, nullptr};  // [n_segs][N - hop]
     double* d_taild[2] = {nullptr, nullptr}; // the same for the fp64 fused kernel
     int g_max = 0;
-    // persistent path (k_gl_persist): d_yw holds both ping-pong buffers, d_ctl = {err, pad[3], flags[n_wg]}
+    // persistent path (k_gl_persist): d_yw holds its three output buffers, d_ctl = {err, pad[3]}
     int persist = 0;
     int n_wg = 0;
     int err_slot = -1;
@@ -535,18 +537,24 @@ static bool fused_applicable(const gomel_config& c) { return fused_shift(c) != 0
 static bool persist_geometry_ok(const gomel_config& c) {
     return gomel_supported_n(c.resolut) && c.window % 4 == 0 && c.window > 0 && (c.resolut - 1) / c.window <= kPersistMaxNb;
 }
-template <int N> static int persist_census_n(int device) {
-    int per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist<N>, 128, 0) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+template <int N, int OCC> static int persist_census_n(int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist<N, OCC>, 128, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    return per_cu * prop.multiProcessorCount;
+    return per_cu * cus;
 }
-static int persist_census(gomel_handle* h) {   // caller holds a DeviceGuard
-    if (h->persist_census < 0) { int n = 0; GOMEL_DISPATCH_N(h->cfg.resolut, n = persist_census_n<NN>(h->device)); h->persist_census = n; }
-    return h->persist_census;
+static int persist_census(gomel_handle* h, int occ) {   // caller holds a DeviceGuard
+    int& c = h->persist_census[occ - 1];
+    if (c < 0) {
+        int n = 0;
+        if (occ == 1) { GOMEL_DISPATCH_N(h->cfg.resolut, n = (persist_census_n<NN, 1>(h->device))); }
+        else { GOMEL_DISPATCH_N(h->cfg.resolut, n = (persist_census_n<NN, 2>(h->device))); }
+        c = n;
+    }
+    return c;
 }
 
 // Batch size (total frames) from which the fused kernel beats the generic pair.  A fused stream walks at least gmin =
@@ -743,14 +751,21 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         const size_t tail_bytes = b->segs.size() * (size_t)(N - c.window) * 4;
         if (b->fast) HIPCHK(hipMemsetAsync(b->d_tail[0], 0, tail_bytes, s));  // x0 has no tail contributions
         if (b->persist) {   // all I iterations in one launch; x_I = overlap-add of the last iteration's frames
+            const size_t buf_floats = (size_t)b->total_frames * N;
             HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
+            HIPCHK(hipMemsetAsync(b->d_yw, 0xff, 3 * buf_floats * 4, s));   // every slot starts as "not stored yet" (kPersistSentinel)
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
-            float* yw1 = b->d_yw + (size_t)b->total_frames * N;
-            GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist<NN>, dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, b->d_nyq,
-                                                   b->d_yw, yw1, b->d_ctl + 4, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->dt));
+            if (b->persist == 1) {
+                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, 1>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, b->d_nyq,
+                                                       b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
+            } else {
+                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, 2>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, b->d_nyq,
+                                                       b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
+            }
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
-            hipLaunchKernelGGL(k_ola<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, ((I - 1) & 1) ? yw1 : b->d_yw, b->d_x[1], N, c.window);
-            cur = 1;
+            const float* y_last = b->d_yw + (size_t)((I - 1) % 3) * buf_floats;
+            if (b->io32) hipLaunchKernelGGL(k_ola_out<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out32, N, c.window);
+            else hipLaunchKernelGGL(k_ola_out<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out64, N, c.window);
         }
         for (int it = 0; it < I && !b->persist; it++) {
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
@@ -767,7 +782,9 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                                   hipLaunchKernelGGL((k_spec_writeback<NN, v2f>), dim3((unsigned)((b->total_frames + SPB - 1) / SPB)), dim3(128), 0, s, b->d_x[cur ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt); });
         }
         const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
-        if (b->io32) {
+        if (b->persist) {
+            // k_ola_out has written the waveforms
+        } else if (b->io32) {
             hipLaunchKernelGGL(k_finalize<float>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out32, b->total_len);
             if (b->fast) hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out32, N - c.window, c.window);
         } else {
@@ -1029,23 +1046,27 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         b->total_frames += d.frames; b->total_pairs += (int64_t)n_pairs[u];
         b->max_len = std::max(b->max_len, d.len);
     }
-    // Path choice: the fused kernel walks consecutive frames per stream, which only pays once there are enough frames to fill
-    // the chip (fused_min_frames); below that every frame in parallel (generic kernels) is faster.
+    // Path choice.  A batch whose frames all fit the chip at once (one utterance, a few short ones) takes the persistent kernel:
+    // every iteration in one launch, ~9 us per iteration whatever the frame count.  Beyond that the fused kernel, which walks
+    // consecutive frames per stream and so only pays once there are enough frames to fill the chip (fused_min_frames); in
+    // between (and for hops neither takes) every frame in parallel, two launches per iteration (generic kernels).
     b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
     if (h->generic && (b->io32 || b->want_spec)) return GOMEL_ERR_UNSUPPORTED_N;
-    b->fast = (!b->want_spec && h->path_mode != 1 && fused_applicable(c) && (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;   // (fused_applicable is false for generic lengths)
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
-    // ... and below the fused kernel's range, when every frame's stream fits the chip at once (one utterance, a few short ones),
-    // the persistent kernel runs all I iterations in one launch instead of 2 I.
-    if (!b->fast && !b->precise && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && I >= 2) {
+    if (!b->precise && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && I >= 2) {
         const int spw = 128 / (N / 32);                                  // streams (frames) per workgroup
         const int64_t n_wg = (b->total_frames + spw - 1) / spw;
-        if (!h->persist_off && h->err_slab && !h->err_free.empty() && n_wg <= persist_census(h) &&
-            b->total_frames * (int64_t)N < ((int64_t)1 << 28) && b->max_len < ((int64_t)1 << 30)) {
-            b->persist = 1; b->n_wg = (int)n_wg;
+        int max_frames = 0;
+        for (const UttDesc& d : b->utts) max_frames = std::max(max_frames, d.frames);
+        if (!h->persist_off && h->err_slab && !h->err_free.empty() && n_wg <= persist_census(h, 2) &&
+            b->total_frames * (int64_t)N < ((int64_t)1 << 28) && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20)) {
+            b->persist = n_wg <= persist_census(h, 1) ? 1 : 2;   // = the kernel's OCC: one wave per SIMD while the batch fits that way
+            b->n_wg = (int)n_wg;
             b->err_slot = h->err_free.back(); h->err_free.pop_back();
         }
     }
+    b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && fused_applicable(c) &&
+               (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;   // (fused_applicable is false for generic lengths)
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     int rc = GOMEL_OK;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
@@ -1063,9 +1084,9 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
             alloc((void**)&b->d_taild[0], b->segs.size() * (size_t)(N - hop) * 8);
             alloc((void**)&b->d_taild[1], b->segs.size() * (size_t)(N - hop) * 8);
-            if (!rc && hipMemcpy(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+            if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it; every reader runs on h->stream
             for (int i = 0; i < 2; i++)
-                if (!rc && hipMemset(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8) != hipSuccess) rc = GOMEL_ERR_HIP;
+                if (!rc && hipMemsetAsync(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
         } else {
             alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8);
             alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
@@ -1076,33 +1097,24 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
         alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
         if (!b->fast) alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
-        if (!b->fast) alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4 * (b->persist ? 2 : 1));
+        if (!b->fast) alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4 * (b->persist ? 3 : 1));
         if (b->persist) {
-            b->ctl_bytes = (16 + (size_t)b->n_wg * 4 + 15) & ~(size_t)15;
+            b->ctl_bytes = 16;
             alloc((void**)&b->d_ctl, b->ctl_bytes);
             alloc((void**)&b->d_frame_utt, (size_t)b->total_frames * 4);
-            std::vector<int32_t> fu((size_t)b->total_frames);
-            for (size_t u = 0; u < n_utt; u++)
-                for (int f = 0; f < b->utts[u].frames; f++) fu[(size_t)b->utts[u].fbase + f] = (int32_t)u;
-            if (!rc && hipMemcpy(b->d_frame_utt, fu.data(), fu.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
         }
         if (b->fast) {
             plan_segments(b);
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
             alloc((void**)&b->d_tail[0], b->segs.size() * (size_t)(N - hop) * 4);
             alloc((void**)&b->d_tail[1], b->segs.size() * (size_t)(N - hop) * 4);
-            if (!rc && hipMemcpy(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
+            if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it; every reader runs on h->stream
             for (int i = 0; i < 2; i++)  // tails of segments without a successor are never written: they must read as zeros
-                if (!rc && hipMemset(b->d_tail[i], 0, b->segs.size() * (size_t)(N - hop) * 4) != hipSuccess) rc = GOMEL_ERR_HIP;
+                if (!rc && hipMemsetAsync(b->d_tail[i], 0, b->segs.size() * (size_t)(N - hop) * 4, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
         }
     }
     for (auto& e : b->ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = GOMEL_ERR_HIP;
-    if (!rc && I > 0 && !b->fast) {
-        std::vector<int64_t> fx((size_t)b->total_frames);
-        for (size_t u = 0; u < n_utt; u++)
-            for (int f = 0; f < b->utts[u].frames; f++) fx[(size_t)b->utts[u].fbase + f] = b->utts[u].xoff + (int64_t)f * hop;
-        if (hipMemcpy(b->d_frame_xoff, fx.data(), fx.size() * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GOMEL_ERR_HIP;
-    }
+    // (the per-frame index tables d_frame_xoff / d_frame_utt are filled on the device, behind the utterance descriptors: batch_upload_impl)
     if (rc) return rc;
     guard.b = nullptr;
     *out = b;
@@ -1145,6 +1157,9 @@ static int batch_upload_impl(gomel_batch* b, const void* const* mel, const void*
             HIPCHK(hipMemcpyAsync((char*)b->d_x0 + (size_t)b->utts[u].xoff * esz, x0[u], (size_t)b->utts[u].len * esz, hipMemcpyDefault, st));
     }
     HIPCHK(hipMemcpyAsync(b->d_utts, b->utts.data(), b->n_utt * sizeof(UttDesc), hipMemcpyHostToDevice, st));
+    if (b->d_frame_xoff || b->d_frame_utt)
+        hipLaunchKernelGGL(k_frame_index, dim3((unsigned)((b->total_frames + 255) / 256)), dim3(256), 0, st, b->d_utts, (int)b->n_utt, b->total_frames, b->h->cfg.window,
+                           b->d_frame_xoff, b->d_frame_utt);
     if (wait || pin_here) HIPCHK(hipStreamSynchronize(st));   // the local pins must outlive the copies
     b->uploaded = true;
     return GOMEL_OK;

@@ -4,7 +4,7 @@ import numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gomel_amd
 I = 60
-for N, hop, K, fmax, Fs in ((4096, 1280, 192, 16000.0, (16, 64, 128, 200, 256, 257, 300, 342, 400, 512)), (1024, 256, 80, 8000.0, (64, 256, 512, 1024, 2048))):
+for N, hop, K, fmax, Fs in ((4096, 1280, 192, 16000.0, (16, 64, 128, 200, 256, 257, 300, 342, 400, 512, 684, 1024)), (1024, 256, 80, 8000.0, (64, 256, 512, 1024, 2048, 4096))):
     m = gomel_amd.NewMel()
     m.NumMels, m.MelFmax, m.Window, m.Resolut, m.GriffinLimIterations = K, fmax, hop, N, I
     e = m.engine()

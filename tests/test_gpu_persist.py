@@ -60,6 +60,23 @@ def test_persistent_equals_generic_bit_for_bit(oracle, N, hop, K):
         ep.close(); eg.close()
 
 
+@pytest.mark.parametrize("N,hop,K,frames", [(4096, 1280, 192, [342, 342, 300]), (4096, 256, 96, [700]), (1024, 256, 80, [900, 900, 900, 3, 1]),
+                                            (2048, 516, 80, [1500]), (256, 16, 40, [2000] * 5 + [17])])
+def test_two_waves_per_simd_build_equals_generic_bit_for_bit(oracle, N, hop, K, frames):
+    """Batches too big for one wave per SIMD run the kernel's 256-VGPR build (tables re-read through the L1, two covering frames in
+    flight): same sums, same bits."""
+    mels = logmels(oracle, frames, K, seed0=40)
+    seeds = list(range(len(frames)))
+    mp, ep = engine(N, hop, K, 5, PERSIST)
+    outp, tmp = run(ep, mels, seeds)
+    mg, eg = engine(N, hop, K, 5, GENERIC)
+    outg, _ = run(eg, mels, seeds)
+    assert tmp["fast_path"] == 2
+    for a, b in zip(outp, outg):
+        assert np.array_equal(a, b)
+    ep.close(); eg.close()
+
+
 def test_towavpng_single_utterance_uses_it_and_matches_the_oracle(oracle):
     """BASELINE configs[1]: one 10 s utterance at 44.1 kHz, 342 frames, 60 iterations -- the library's own choice (path 0)."""
     N, hop, K, F, I = 4096, 1280, 192, 342, 60
@@ -85,14 +102,15 @@ def test_towavpng_single_utterance_uses_it_and_matches_the_oracle(oracle):
 def test_batches_beyond_the_chip_fall_to_the_other_kernels(oracle):
     import gomel_amd
     m, e = engine(4096, 1280, 192, 3, 0, fmax=16000.0)
-    for n_utt, frames, want in ((1, 300, 2), (1, 512, 2), (2, 300, 0), (8, 300, 1)):
+    # 512 workgroups at one wave per SIMD, 1024 at two (the 256-VGPR build of the kernel); then generic up to the fused kernel's 1536
+    for n_utt, frames, want in ((1, 300, 2), (1, 512, 2), (2, 300, 2), (1, 1024, 2), (1, 1025, 0), (4, 300, 0), (8, 300, 1)):
         b = gomel_amd.Batch(e, [frames * 192] * n_utt)
         b.upload(logmels(oracle, [frames] * n_utt, 192), None, list(range(n_utt)))
         assert b.run_timed()["fast_path"] == want, (n_utt, frames)
         b.close()
     e.set_path(PERSIST)
     with pytest.raises(gomel_amd.GomelError):
-        gomel_amd.Batch(e, [600 * 192])           # required, but 600 frames do not fit the chip at once
+        gomel_amd.Batch(e, [1100 * 192])          # required, but 1100 frames do not fit the chip at once
     e.close()
 
 

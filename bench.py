@@ -75,12 +75,15 @@ def build_engine(fields, device, tables=None):
     return gomel_amd.Engine(m._config(), tables=tables)
 
 
+PATHS = ("generic", "fused", "persistent")      # gomel_timing.fast_path
+
+
 def committed_traffic(workload, fast_path):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes (profiles/traffic.json): counters
     cannot be read from inside the timed process, so this figure is a label from an earlier profile of the same kernel."""
     try:
         with open(TRAFFIC_JSON) as f:
-            e = json.load(f).get("%s:%s" % (workload, "fused" if fast_path else "generic"))
+            e = json.load(f).get("%s:%s" % (workload, PATHS[fast_path]))
         return (None, None) if e is None else (e.get("hbm_bytes_per_launch"), "profiles/traffic.json [%s] (separate rocprofv3 --pmc passes, not this run)" % e.get("from", "?"))
     except (OSError, ValueError):
         return None, None
@@ -363,7 +366,7 @@ def main():
             el2, _, _, _ = host_to_host(e2, f2, u2, fr2, 0, 20, 2, lambda: None)
             single = {"workload": d2, "resident_frames_per_s": fps2, "resident_ms_per_utterance": u2 * fr2 / fps2 * 1e3,
                       "host_to_host_ms_per_utterance": el2 / 20 * 1e3, "real_time_factor_host_to_host": u2 * fr2 * 20 / el2 * f2["Window"] / sr2,
-                      "kernel_path": "fused" if tm2["fast_path"] else "generic"}
+                      "kernel_path": PATHS[tm2["fast_path"]]}
             e2.close()
         el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
         pageable = min(n_utt, BLOCK) * frames * 3 / el_p
@@ -393,7 +396,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "utterances_per_gpu": n_utt, "frames_per_utterance": frames, "resolut": N, "window_hop": hop,
                        "num_mels": fields["NumMels"], "iterations": I, "parallelism": "utterance-sharded x%d" % world,
-                       "kernel_path": "fused" if tm["fast_path"] else "generic",
+                       "kernel_path": PATHS[tm["fast_path"]],
                        "timed_region": "gomel_from_mel_batch host-to-host (pinned fp64 buffers, H2D + all device work + D2H), %d utterances per call" % min(n_utt, BLOCK)},
             "real_time_factor": value * hop / sr,
             "resident_frames_per_s": res_fps,

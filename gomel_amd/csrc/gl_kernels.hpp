@@ -140,6 +140,7 @@ static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const 
     const size_t row_bytes = (size_t)(N / 2) * sizeof(MagT), budget = 64 * 1024;
     int fpb = kMagFramesPerBlock;
     while (fpb > 1 && (size_t)fpb * K * 8 + row_bytes > budget) fpb--;
+    while (fpb > 1 && (frames + fpb - 1) / fpb < 1024) fpb--;   // a short batch (one utterance) spreads over the chip instead: 28 -> 7 us at 342 frames
     const size_t shmem = (size_t)fpb * K * 8 + row_bytes;
     const unsigned blocks = (unsigned)((frames + fpb - 1) / fpb);
     hipError_t e = hipSuccess;
@@ -422,12 +423,15 @@ GL_DEV v4f quad_from_rows(v2f r0, v2f r1, bool even) {
 //     L1 line) and re-loads those that still show the sentinel in ANY of their four words, so a torn 16-byte read cannot pass.
 //     It cannot see y_P(i-3) there: it has consumed y_P(i-1) already, and P drained the sentinel that replaced y_P(i-3) before
 //     storing y_P(i-1).
-// The host fills all three buffers with the sentinel before every launch.  Every stream must be resident (the host checks the
+// The host fills buf[0] with the sentinel before every launch (what a previous launch left in buf[1] / buf[2] is covered by the
+// same argument: P overwrites its slots there with the sentinel in iterations 0 and 1 and drains before storing y_P(0) / y_P(1),
+// which every reader of those slots consumes first).  Every stream must be resident (the host checks the
 // occupancy census before choosing this path); the re-load loop is bounded by a wall-clock limit, a timeout -- neighbours not
 // resident, or data that really contains the sentinel pattern -- sets *err, after which every stream runs through without
 // waiting, and the host recomputes the batch with the per-iteration kernels.
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-constexpr int kPersistMaxNb = 15;            // neighbours on each side: (N-1)/hop <= 15, i.e. hop >= N/16
+constexpr int kPersistMaxNb = 15;            // neighbours on each side the kernel handles: (N-1)/hop <= 15, i.e. hop >= N/16
+constexpr int kPersistAutoNb = 7;            // ... and up to which the library chooses it by itself (hop >= N/8)
 constexpr unsigned kPersistSpinTicks = 20u * 100000u;   // default spin limit: 20 ms of the 100 MHz wall clock
 constexpr unsigned kPersistSentinel = 0xffffffffu;
 
@@ -436,15 +440,20 @@ GL_DEV bool persist_fresh(v4u q) { return q.x != kPersistSentinel && q.y != kPer
 #ifdef GOMEL_STAMPS   // diagnostic build only (scripts/stamp_probe.py, stamp_persist.py): per-phase cycle sums, all waves
 __device__ unsigned long long g_stamp_acc[21];
 #endif
-// OCC = waves per SIMD the kernel is built for: 1 = everything in registers (512 VGPRs: twiddles, window, four covering frames'
-// quads in flight), 2 = twice the resident streams (256 VGPRs: twiddles and window re-read through the L1, which nothing
-// invalidates here; two covering frames in flight).
-template <int N, int OCC>
+// OCC = waves per SIMD the kernel is built for: 1 = 512 VGPRs (twiddles, window, spectral operands and four covering frames' quads
+// in registers), 2 = twice the resident streams (256 VGPRs: tables re-read through the L1, which nothing invalidates here; two
+// covering frames in flight).  DEPTH = covering frames in flight per row pair during the gather (each group of DEPTH is one round
+// trip to memory, ~2.6 us): 4 at OCC 1, 2 at OCC 2.  (8, for hops below N/4, was measured SLOWER than two rounds of 4 -- 0.83 vs
+// 0.76 ms at N 2048 / hop 256 -- because its 256 registers of quads leave none for the tables; not instantiated.)
+template <int N, int OCC, int DEPTH>
 __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
                                                       const float* __restrict__ mag, const float* __restrict__ nyq, float* yw,
                                                       unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb) {
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = 128 / T;
+    // LEAN: the registers go to the gather (OCC 2: there are only 256; DEPTH 8: 64 quads in flight) -- twiddles, window, spectral
+    // operands and the frame's own previous output are re-read (L1 / the exchange buffers) instead of kept
+    constexpr bool LEAN = OCC != 1 || DEPTH == 8;
     __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
     int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
     v2f* my = lds + stream * G::LDS_SLOTS;
     // every twiddle operand of this lane in registers for the whole call (the launch runs one wave per SIMD: 512 VGPRs)
     v2f w2r[16], w1r[16];
-    if constexpr (OCC == 1) {
+    if constexpr (!LEAN) {
 #pragma unroll
         for (int uu = 0; uu < G::NB2; uu++)
 #pragma unroll
@@ -463,8 +472,9 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
 #pragma unroll
             for (int q = 0; q < G::R1; q++) w1r[uu + G::NB1 * q] = tb.tw1[q * G::C1 + t + T * uu];
     }
-    const Twiddles<v2f> tw{tb.tw1, tb.tw2, nullptr, OCC == 1 ? w1r : nullptr, OCC == 1 ? 15 : 0, OCC == 1 ? w2r : nullptr};
-    constexpr int DEPTH = OCC == 1 ? 4 : 2;   // covering frames in flight per row pair
+    const Twiddles<v2f> tw{tb.tw1, tb.tw2, nullptr, !LEAN ? w1r : nullptr, !LEAN ? 15 : 0, !LEAN ? w2r : nullptr};
+    static_assert(DEPTH == 2 || DEPTH == 4 || DEPTH == 8, "gather depth");
+    typedef unsigned long long mask_t;   // one bit per quad in flight: 8 row pairs x DEPTH
     auto sync = [] {
         if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -475,13 +485,13 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
     // this frame's constants: window pairs, spectral-step operands, magnitudes
     const v2f* w2 = reinterpret_cast<const v2f*>(tb.window);
     v2f w[16], wn[8];
-    if constexpr (OCC == 1) {
+    if constexpr (!LEAN) {
 #pragma unroll
         for (int j = 0; j < 16; j++) w[j] = w2[t + T * j];
     }
     MagRaw mraw;
     MagRegs mr;
-    if constexpr (OCC == 1) {
+    if constexpr (!LEAN) {
         load_mags_raw<G>(mraw, t, mag + frame * G::C, nyq + frame);
         load_wn<G>(wn, t, tb.wn);
         finish_mags(mr, mraw, t == 0);
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
         // OCC 2: the table addresses of an iteration (window, twiddles, magnitudes: some 40 64-bit pointers) are loop invariants the
         // compiler would hoist and then spill; an opaque copy of the lane index makes it rebuild them where they are used
         int tl = t;
-        if constexpr (OCC != 1) asm volatile("" : "+v"(tl));
+        if constexpr (LEAN) asm volatile("" : "+v"(tl));
         if (it == 0) {
             typedef v2f v2f_a4 __attribute__((aligned(4)));
             const v2f_a4* xs = reinterpret_cast<const v2f_a4*>(x0 + u.xoff + (int64_t)f * hop);
@@ -535,13 +545,13 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
             for (int jp = 0; jp < 8; jp++) acc[jp] = v4f{0.f, 0.f, 0.f, 0.f};
             for (int dk = 0; dk <= nb; dk += DEPTH) {   // cnt <= nb + 1; DEPTH frames' copies in flight per row pair (up to 32 x 16 B per lane)
                 v4u a[8][DEPTH];
-                unsigned todo = 0;   // bit 4 jp + q: the quad is a neighbour's and not in yet
+                mask_t todo = 0;   // bit DEPTH jp + q: the quad is a neighbour's and not in yet
 #pragma unroll
                 for (int jp = 0; jp < 8; jp++)
 #pragma unroll
                     for (int q = 0; q < DEPTH; q++) {
                         a[jp][q] = v4u{0u, 0u, 0u, 0u};
-                        if (dk + q < (geo[jp] >> 20 & 31) && (OCC != 1 || dk + q != (geo[jp] >> 25 & 31))) todo |= 1u << (DEPTH * jp + q);
+                        if (dk + q < (geo[jp] >> 20 & 31) && (LEAN || dk + q != (geo[jp] >> 25 & 31))) todo |= (mask_t)1 << (DEPTH * jp + q);
                     }
                 if (dead) todo = 0;
                 unsigned long long t0 = 0;
@@ -550,17 +560,17 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
                     for (int jp = 0; jp < 8; jp++)
 #pragma unroll
                         for (int q = 0; q < DEPTH; q++)
-                            if (todo & (1u << (DEPTH * jp + q)))
+                            if (todo & ((mask_t)1 << (DEPTH * jp + q)))
                                 a[jp][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(4 * T * jp) * 4u + (unsigned)((geo[jp] & 0xfffff) + dk + q) * kstep, (unsigned)prev * buf_bytes, 16);   // aux 16 = sc1
 #pragma unroll
                     for (int jp = 0; jp < 8; jp++)
 #pragma unroll
                         for (int q = 0; q < DEPTH; q++)
-                            if ((todo & (1u << (DEPTH * jp + q))) && persist_fresh(a[jp][q])) todo &= ~(1u << (DEPTH * jp + q));
+                            if ((todo & ((mask_t)1 << (DEPTH * jp + q))) && persist_fresh(a[jp][q])) todo &= ~((mask_t)1 << (DEPTH * jp + q));
 #ifdef GOMEL_STAMPS
                     st.acc[2] += 1;   // load rounds
 #endif
-                    if (!__any(todo != 0u)) break;
+                    if (!__any(todo != 0)) break;
                     // some neighbour has not stored yet: look again, but not for ever
                     // (the re-load goes out at once: a look at *err costs a round trip of its own, so only every 16th time)
                     if (t0 == 0) t0 = wall_clock64();
@@ -575,17 +585,17 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
 #pragma unroll
                 for (int jp = 0; jp < 8; jp++)
 #pragma unroll
-                    for (int q = 0; q < DEPTH; q++) acc[jp] += (OCC == 1 && dk + q == (geo[jp] >> 25 & 31)) ? ownq[jp] : __builtin_bit_cast(v4f, a[jp][q]);   // absent frames add the zeros a[][] started as
+                    for (int q = 0; q < DEPTH; q++) acc[jp] += (!LEAN && dk + q == (geo[jp] >> 25 & 31)) ? ownq[jp] : __builtin_bit_cast(v4f, a[jp][q]);   // absent frames add the zeros a[][] started as
             }
             st.mark(0);
 #ifdef GOMEL_STAMPS_RELOAD   // diagnostic: the same loads once more, nobody writing: the bare round trip
             {
-                v4u r[8][4];
+                v4u r[8][DEPTH];
 #pragma unroll
                 for (int jp = 0; jp < 8; jp++)
 #pragma unroll
                     for (int q = 0; q < DEPTH; q++)
-                        if (q < (geo[jp] >> 20 & 31) && q != (geo[jp] >> 25 & 31)) r[jp][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(4 * T * jp) * 4u + (unsigned)((geo[jp] & 0xfffff) + q) * kstep, (unsigned)prev * buf_bytes, 16);
+                        if (jp < GOMEL_STAMPS_RELOAD && (threadIdx.x < GOMEL_STAMPS_RELOAD_T) && q < (geo[jp] >> 20 & 31) && q != (geo[jp] >> 25 & 31)) r[jp][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(4 * T * jp) * 4u + (unsigned)((geo[jp] & 0xfffff) + q) * kstep, (unsigned)prev * buf_bytes, 16);
                         else r[jp][q] = v4u{0u, 0u, 0u, 0u};
                 unsigned x_ = 0;
 #pragma unroll
@@ -605,25 +615,25 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
             for (int jp = 0; jp < 8; jp++) __builtin_amdgcn_raw_buffer_store_b128(sentinel, rs, my_off + (unsigned)(4 * T * jp) * 4u, (unsigned)next * buf_bytes, 16);
         }
         st.mark(1);
-        if constexpr (OCC != 1) {
+        if constexpr (LEAN) {
 #pragma unroll
             for (int j = 0; j < 16; j++) w[j] = w2[tl + T * j];
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= w[j];
-        if constexpr (OCC != 1) {   // the spectral step's operands: issued here, needed a forward FFT later
+        if constexpr (LEAN) {   // the spectral step's operands: issued here, needed a forward FFT later
             load_mags_raw<G>(mraw, tl, mag + frame * G::C, nyq + frame);
             load_wn<G>(wn, tl, tb.wn);
         }
         fft_forward<G>(v, my, tl, tw, sync);
         st.mark(3);
-        if constexpr (OCC != 1) finish_mags(mr, mraw, t == 0);
+        if constexpr (LEAN) finish_mags(mr, mraw, t == 0);
         spectral_apply<G>(v, t, mr, wn);
         st.mark(4);
-        if constexpr (OCC != 1) asm volatile("" : "+v"(tl));
+        if constexpr (LEAN) asm volatile("" : "+v"(tl));
         fft_inverse<G>(v, my, tl, tw, sync);
         st.mark(5);
-        if constexpr (OCC != 1) {
+        if constexpr (LEAN) {
             asm volatile("" : "+v"(tl));
 #pragma unroll
             for (int j = 0; j < 16; j++) w[j] = w2[tl + T * j];
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
 #pragma unroll
         for (int jp = 0; jp < 8; jp++) {
             const v4f q = quad_from_rows(v[2 * jp] * w[2 * jp], v[2 * jp + 1] * w[2 * jp + 1], even);
-            if constexpr (OCC == 1) ownq[jp] = q;
+            if constexpr (!LEAN) ownq[jp] = q;
             if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q), rs, my_off + (unsigned)(4 * T * jp) * 4u, (unsigned)cur * buf_bytes, 16);   // aux 16 = sc1
         }
         st.mark(6);

@@ -539,7 +539,7 @@ static bool persist_geometry_ok(const gomel_config& c) {
 }
 template <int N, int OCC> static int persist_census_n(int device) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist<N, OCC>, 128, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist<N, OCC, (OCC == 1 ? 4 : 2)>, 128, 0) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
@@ -753,15 +753,16 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         if (b->persist) {   // all I iterations in one launch; x_I = overlap-add of the last iteration's frames
             const size_t buf_floats = (size_t)b->total_frames * N;
             HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
-            HIPCHK(hipMemsetAsync(b->d_yw, 0xff, 3 * buf_floats * 4, s));   // every slot starts as "not stored yet" (kPersistSentinel)
+            // buf[0] starts as "not stored yet" (kPersistSentinel); the streams themselves reset their slots of buf[1] and buf[2] in
+            // iterations 0 and 1, and drain that before anything a reader of those slots could have waited for
+            HIPCHK(hipMemsetAsync(b->d_yw, 0xff, buf_floats * 4, s));
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
-            if (b->persist == 1) {
-                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, 1>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, b->d_nyq,
-                                                       b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
-            } else {
-                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, 2>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, b->d_nyq,
-                                                       b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
-            }
+#define GOMEL_PERSIST_LAUNCH(OCC, DEPTH)                                                                                                                     \
+    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, OCC, DEPTH>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, \
+                                           b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt))
+            if (b->persist == 2) { GOMEL_PERSIST_LAUNCH(2, 2); }
+            else { GOMEL_PERSIST_LAUNCH(1, 4); }   // (eight covering frames in flight, for hops below N/4, measured slower than two rounds of four: its registers come out of the tables')
+#undef GOMEL_PERSIST_LAUNCH
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
             const float* y_last = b->d_yw + (size_t)((I - 1) % 3) * buf_floats;
             if (b->io32) hipLaunchKernelGGL(k_ola_out<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out32, N, c.window);
@@ -1053,7 +1054,11 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
     if (h->generic && (b->io32 || b->want_spec)) return GOMEL_ERR_UNSUPPORTED_N;
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
-    if (!b->precise && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && I >= 2) {
+    // (every frame gathers its whole window from the covering frames, N/hop times the bytes of k_ola's single pass: beyond eight
+    // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms
+    // generic, hop 128 1.25 against 1.14 -- so the library picks the kernel down to hop = N/8 only; gomel_set_path(h, 3) still runs it)
+    const bool persist_pays = (N - 1) / hop <= kPersistAutoNb || h->path_mode == 3;
+    if (!b->precise && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && persist_pays && I >= 2) {
         const int spw = 128 / (N / 32);                                  // streams (frames) per workgroup
         const int64_t n_wg = (b->total_frames + spw - 1) / spw;
         int max_frames = 0;

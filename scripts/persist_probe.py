@@ -31,7 +31,7 @@ for name, (N, hop, K, fmax, frames, I) in {"cfg2 single 10 s utterance": (4096, 
                                            "cfg2 two utterances 200+150": (4096, 1280, 192, 16000.0, [200, 150], 60),
                                            "TTS 8 x 100 frames": (1024, 256, 80, 8000.0, [100] * 8, 60),
                                            "TTS 1 x 400 frames": (1024, 256, 80, 8000.0, [400], 60),
-                                           "N 2048 hop 256 1 x 500": (2048, 256, 160, 8000.0, [500], 60)}.items():
+                                           "N 2048 hop 256 1 x 500": (2048, 256, 160, 8000.0, [500], 60), "N 2048 hop 128 1 x 500": (2048, 128, 160, 8000.0, [500], 60), "N 1024 hop 64 4 x 500": (1024, 64, 80, 8000.0, [500] * 4, 60)}.items():
     og, tg, tmg, hg = go(N, hop, K, fmax, frames, I, 1)
     op, tp, tmp, hp = go(N, hop, K, fmax, frames, I, 0)
     same = all(np.array_equal(a, b) for a, b in zip(og, op))

@@ -112,6 +112,13 @@ def test_batches_beyond_the_chip_fall_to_the_other_kernels(oracle):
     with pytest.raises(gomel_amd.GomelError):
         gomel_amd.Batch(e, [1100 * 192])          # required, but 1100 frames do not fit the chip at once
     e.close()
+    # hops below N/8: every frame would gather sixteen covering frames -- the library leaves those to the generic kernels
+    for N, hop, want in ((2048, 256, 2), (2048, 128, 0), (1024, 64, 0), (1024, 128, 2)):
+        m2, e2 = engine(N, hop, 80, 3, 0)
+        b = gomel_amd.Batch(e2, [100 * 80])
+        b.upload(logmels(oracle, [100], 80), None, [0])
+        assert b.run_timed()["fast_path"] == want, (N, hop)
+        b.close(); e2.close()
 
 
 def test_timeout_recomputes_with_the_generic_kernels(oracle, monkeypatch):
@@ -135,3 +142,49 @@ def test_timeout_recomputes_with_the_generic_kernels(oracle, monkeypatch):
     assert np.array_equal(out2, ref)
     assert tm2["fast_path"] in (0, 2)       # 0 once a wait has really timed out; 2 if every poll happened to hit first time
     e.close(); eg.close()
+
+
+def test_repeated_runs_and_a_busy_chip_never_change_a_bit(oracle):
+    """The hazard of an in-launch exchange is a RARE stale read.  One batch object run 150 times (its buffers keep the previous
+    run's frames: exactly what a stale read would pick up), alone and while a second handle keeps the chip busy with the fused
+    kernel from another thread -- every waveform must equal the generic kernels' bit for bit.  (Under the load a launch may give
+    up and be recomputed: also right, and the handle then stays on the generic path.)"""
+    import threading
+    import gomel_amd
+    N, hop, K, I = 4096, 1280, 192, 12
+    frames = [342, 100, 57]
+    mels = logmels(oracle, frames, K, seed0=70)
+    mg, eg = engine(N, hop, K, I, GENERIC, fmax=16000.0)
+    ref, _ = run(eg, mels, [1, 2, 3])
+    eg.close()
+    m, e = engine(N, hop, K, I, 0, fmax=16000.0)
+    b = gomel_amd.Batch(e, [x.shape[0] for x in mels])
+    b.upload(mels, None, [1, 2, 3])
+    paths = set()
+    for rep in range(150):
+        paths.add(b.run_timed()["fast_path"])
+        out = b.download()
+        assert all(np.array_equal(a, r) for a, r in zip(out, ref)), rep
+    assert paths == {2}
+    stop = threading.Event()
+
+    def hammer():
+        m2, e2 = engine(N, hop, K, 4, 2, fmax=16000.0)
+        big = logmels(oracle, [400] * 8, K, seed0=90)
+        b2 = gomel_amd.Batch(e2, [x.shape[0] for x in big])
+        b2.upload(big, None, list(range(8)))
+        while not stop.is_set():
+            b2.run(); b2.sync()
+        b2.close(); e2.close()
+
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        for rep in range(60):
+            b.run()
+            out = b.download()
+            assert all(np.array_equal(a, r) for a, r in zip(out, ref)), ("busy", rep)
+    finally:
+        stop.set()
+        th.join()
+    b.close(); e.close()

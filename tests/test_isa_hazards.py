@@ -101,3 +101,23 @@ def test_no_fused_kernel_instantiation_spills(isa):
     body = body[:next(i for i, l in enumerate(body) if "s_endpgm" in l)]
     assert not any("scratch_" in l for l in body)
     assert sum("global_load_dwordx4" in l for l in body) >= 6      # four magnitude loads + two row pairs per frame
+
+
+def test_persistent_kernel_builds_fit_their_occupancy(isa):
+    """k_gl_persist must have every stream resident: the OCC 1 build may use the whole 512-VGPR file of a lone wave, the OCC 2 build
+    must stay within 256, and neither may spill (the host's occupancy census, and with it the path choice, rests on these numbers).
+    Its exchange must be what DESIGN.md says: write-through (sc1) 16-byte stores, sc1 16-byte loads, no fence."""
+    text = "\n".join(isa)
+    found = re.findall(r"\.name:\s+(_Z12k_gl_persistILi(\d+)ELi(\d+)ELi(\d+)E\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(found) == 10, [f[0] for f in found]          # five frame lengths x (one wave per SIMD, two)
+    for name, n, occ, depth, vgpr, spill in found:
+        assert (int(occ), int(depth)) in ((1, 4), (2, 2))
+        assert int(spill) == 0 and int(vgpr) <= 512 // int(occ), (n, occ, vgpr, spill)
+    body = isa[next(i for i, l in enumerate(isa) if l.startswith("_Z12k_gl_persistILi4096ELi1ELi4EE") and ":" in l):]
+    body = body[:next(i for i, l in enumerate(body) if "s_endpgm" in l)]
+    assert not any("scratch_" in l for l in body)
+    stores = [l for l in body if "buffer_store_dwordx4" in l]
+    loads = [l for l in body if "buffer_load_dwordx4" in l]
+    assert len(stores) >= 16 and all(" sc1" in l for l in stores)        # eight sentinel quads + eight fresh quads per iteration
+    assert len(loads) >= 24 and all(" sc1" in l for l in loads)          # the gather: up to 32 quads, every one of them write-through-coherent
+    assert not any("buffer_inv" in l or "buffer_wbl2" in l for l in body)

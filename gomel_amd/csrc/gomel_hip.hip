@@ -1018,7 +1018,10 @@ int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.g
 // One plan for both kinds of input: log-mel pairs (n_pairs[u] = frames * NumMels) or, for gomel_istft, linear magnitudes
 // (`direct`: n_pairs[u] = frames, rows of N/2+1 doubles).  `iters` >= 0 overrides the configured iteration count.
 enum { BF_DIRECT = 1, BF_IO32 = 2, BF_SPEC = 4 };   // batch_create_common flags
-static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pairs, int flags, int iters, gomel_batch** out) {
+// init_stream: where the batch's descriptor copies and zero-fills are queued -- the stream its upload will use (every reader waits for
+// the upload): the handle's compute stream for the batch API, the upload stream inside the chunk pipeline, where anything queued on
+// the compute stream would sit (and, coming from pageable memory, hold the host) behind the previous chunks' kernels.
+static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pairs, int flags, int iters, gomel_batch** out, hipStream_t init_stream = nullptr) {
     const int direct = (flags & BF_DIRECT) ? 1 : 0;
     if (!h || !n_pairs || !out) return GOMEL_ERR_NULL;
     *out = nullptr;
@@ -1074,6 +1077,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
                (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;   // (fused_applicable is false for generic lengths)
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     int rc = GOMEL_OK;
+    const hipStream_t ist = init_stream ? init_stream : h->stream;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
     alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * (size_t)(N / 2 + 1) * 8 : (size_t)b->total_pairs * 2 * b->esz);
     alloc((void**)&b->d_out, (size_t)b->total_len * b->esz);
@@ -1089,9 +1093,9 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
             alloc((void**)&b->d_taild[0], b->segs.size() * (size_t)(N - hop) * 8);
             alloc((void**)&b->d_taild[1], b->segs.size() * (size_t)(N - hop) * 8);
-            if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it; every reader runs on h->stream
+            if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, ist) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it
             for (int i = 0; i < 2; i++)
-                if (!rc && hipMemsetAsync(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+                if (!rc && hipMemsetAsync(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8, ist) != hipSuccess) rc = GOMEL_ERR_HIP;
         } else {
             alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8);
             alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
@@ -1113,9 +1117,9 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
             alloc((void**)&b->d_tail[0], b->segs.size() * (size_t)(N - hop) * 4);
             alloc((void**)&b->d_tail[1], b->segs.size() * (size_t)(N - hop) * 4);
-            if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it; every reader runs on h->stream
+            if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, ist) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it
             for (int i = 0; i < 2; i++)  // tails of segments without a successor are never written: they must read as zeros
-                if (!rc && hipMemsetAsync(b->d_tail[i], 0, b->segs.size() * (size_t)(N - hop) * 4, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+                if (!rc && hipMemsetAsync(b->d_tail[i], 0, b->segs.size() * (size_t)(N - hop) * 4, ist) != hipSuccess) rc = GOMEL_ERR_HIP;
         }
     }
     for (auto& e : b->ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = GOMEL_ERR_HIP;
@@ -1248,20 +1252,35 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
         if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
         total_frames += (int64_t)(n_pairs[u] / (size_t)K);
     }
-    // Chunk plan: equal chunks of at least ~12k frames (half a round of the chip: the kernels still run at 2.3 of the 2.6 M
-    // frames/s of a big launch, and more chunks expose less of the first upload / last download), at most 16.  Measured and
-    // dropped: small chunks at both ends and big ones in the middle (shares 1:4:7:3:1) -- a pipeline model says 46 ms against 49
-    // for eight equal chunks at config 3, the hardware says 50.3 (scripts/chunk_probe.py).
-    const int64_t kMinChunkFrames = 12288;
-    int n_chunks = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
-    if (const char* e = getenv("GOMEL_CHUNKS")) { int v = atoi(e); if (v > 0) n_chunks = std::min(v, 64); }   // tuning knob
+    // Chunk plan (scripts/chunk_plans.sh, 256 x 400 frames host to host): m full-size chunks' worth of frames, cut as
+    // half : full x (m-1) : half -- the half-size first chunk starts the GPU sooner, the half-size last one leaves less download
+    // exposed at the end (T geometry: 44.3 ms against 45.6 for eight equal chunks, with m = 8).  A full chunk is ~12k frames at
+    // Resolut 4096 (half a round of the chip, 85 us per launch) and ~32k below (shorter frames: the same launch time; at the TTS
+    // geometry three full chunks' worth, 13.5 ms, against 16.1 for eight equal chunks).  More, smaller chunks pay launch overhead and
+    // per-segment prologues; fewer expose more of the first upload and the last download.
+    const int64_t kMinChunkFrames = h->cfg.resolut >= 4096 ? 12288 : 32768;
+    const int m_full = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
+    int n_chunks = total_frames < kMinChunkFrames ? 1 : m_full + 1;
+    std::vector<double> shares;   // relative chunk sizes
+    if (n_chunks > 1) { shares.assign((size_t)n_chunks, 2.0); shares.front() = shares.back() = 1.0; }
+    if (const char* e = getenv("GOMEL_CHUNKS")) { int v = atoi(e); if (v > 0) { n_chunks = std::min(v, 64); shares.assign((size_t)n_chunks, 1.0); } }   // tuning knobs: equal chunks ...
+    if (const char* e = getenv("GOMEL_CHUNK_SHARES")) {                                                                                          // ... or any plan, "1,2,4,2,1"
+        std::vector<double> sv;
+        for (const char* p = e; *p;) { char* q; const double v = strtod(p, &q); if (q == p) break; if (v > 0) sv.push_back(v); p = *q ? q + 1 : q; }
+        if (sv.size() >= 1 && sv.size() <= 64) { shares = sv; n_chunks = (int)sv.size(); }
+    }
     n_chunks = (int)std::min<size_t>((size_t)n_chunks, n_utt);
+    if ((int)shares.size() != n_chunks) shares.assign((size_t)n_chunks, 1.0);
+    double share_sum = 0;
+    for (double v : shares) share_sum += v;
     std::vector<size_t> bounds(1, 0);
     {
         int64_t acc = 0;
         size_t u = 0;
+        double cum = 0;
         for (int c = 1; c < n_chunks; c++) {
-            const int64_t target = total_frames * c / n_chunks;
+            cum += shares[(size_t)c - 1];
+            const int64_t target = (int64_t)((double)total_frames * cum / share_sum);
             while (u < n_utt && acc < target) acc += (int64_t)(n_pairs[u++] / (size_t)K);
             bounds.push_back(std::max(u, bounds.back() + 1));
         }
@@ -1278,7 +1297,7 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
     // At most three chunks hold device buffers at a time (uploading c+1, computing c, downloading c-1): chunk c-2's batch is
     // destroyed -- its buffers go back to the handle's pool -- before chunk c+1's is created, so a call of any size cycles
     // through three sets of buffers instead of allocating one per chunk.
-    auto create = [&](int c) { return batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c]); };
+    auto create = [&](int c) { return batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c], h->up_stream); };
     int rc = create(0);
     std::vector<hipEvent_t> done((size_t)n_chunks, nullptr), up((size_t)n_chunks, nullptr), down((size_t)n_chunks, nullptr);
     std::vector<std::vector<uint64_t>> gseeds((size_t)n_chunks);   // default seed = GLOBAL utterance index, whatever the chunking
@@ -1308,27 +1327,40 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
             return r;
         };
         if (!rc) { std::lock_guard<std::mutex> lk(h->mu); DeviceGuard dg(h->device); rc = upload(0); }
+        // Order matters for keeping the GPU fed: chunk c's kernels are queued FIRST (its upload was issued an iteration ago), and
+        // only then does the host wait for chunk c-2's download, recycle its buffers into chunk c+1 and queue that upload -- all of
+        // which may hold the host for a millisecond or two (the waveforms of c-2 are still coming down; descriptor copies from
+        // pageable memory wait for the upload stream).  The other way round (round 2's first form) the host reached the launches of
+        // chunk c only after chunk c-1 had finished: 0.5 ms of idle GPU per chunk boundary in the kernel trace.
         for (int c = 0; c < n_chunks && !rc; c++) {
+            {
+                std::lock_guard<std::mutex> lk(h->mu);
+                DeviceGuard dg(h->device);
+                gomel_batch* b = chunks[c];
+                const size_t u0 = bounds[c];
+                if (hipStreamWaitEvent(h->stream, up[c], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
+                if (!rc) rc = batch_run_impl(b, nullptr);
+                if (!rc && b->persist) { if (hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP; else rc = persist_verify(b); }
+                if (!rc && (hipEventRecord(done[c], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+                for (size_t u = 0; u < b->n_utt && !rc; u++)
+                    if (hipMemcpyAsync(out[u0 + u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess)
+                        rc = GOMEL_ERR_HIP;
+                if (!rc && hipEventRecord(down[c], h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+            }
+            if (rc || c + 1 >= n_chunks) continue;
             if (c >= 2) {   // chunk c-2 has computed; once its waveforms are down its buffers serve chunk c+1
                 DeviceGuard dg(h->device);
                 if (hipEventSynchronize(down[c - 2]) != hipSuccess) { rc = GOMEL_ERR_HIP; break; }
-                gomel_batch_destroy(chunks[c - 2]); chunks[c - 2] = nullptr;
+                // (not gomel_batch_destroy: that drains the compute stream, i.e. waits for chunks c-1 and c as well; everything that
+                // ever touched this batch's buffers finished before its download did)
+                std::lock_guard<std::mutex> lk(h->mu);
+                batch_free(chunks[c - 2]); chunks[c - 2] = nullptr;
             }
-            if (c + 1 < n_chunks) rc = create(c + 1);                                 // (takes and drops h->mu itself)
+            rc = create(c + 1);                                                       // (takes and drops h->mu itself)
             if (rc) break;
             std::lock_guard<std::mutex> lk(h->mu);
             DeviceGuard dg(h->device);
-            gomel_batch* b = chunks[c];
-            const size_t u0 = bounds[c];
-            if (c + 1 < n_chunks) rc = upload(c + 1);                                   // queued before this chunk's kernels: runs beside them
-            if (!rc && hipStreamWaitEvent(h->stream, up[c], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
-            if (!rc) rc = batch_run_impl(b, nullptr);
-            if (!rc && b->persist) { if (hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP; else rc = persist_verify(b); }
-            if (!rc && (hipEventRecord(done[c], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
-            for (size_t u = 0; u < b->n_utt && !rc; u++)
-                if (hipMemcpyAsync(out[u0 + u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess)
-                    rc = GOMEL_ERR_HIP;
-            if (!rc && hipEventRecord(down[c], h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+            rc = upload(c + 1);                                                        // runs beside chunk c's (and c-1's) kernels
         }
         {
             DeviceGuard dg(h->device);

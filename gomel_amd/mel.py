@@ -175,7 +175,10 @@ class Engine:
         n = len(ms)
         if n == 0:
             return []
-        lens = [self.out_len(len(m)) for m in ms]
+        K, N, hop = self.cfg.num_mels, self.cfg.resolut, self.cfg.window
+        # gomel_out_len without a C call per utterance: N + (F-1) hop, 0 for a length that is no whole number of frames (the C
+        # call below refuses those with GOMEL_ERR_BAD_LENGTH)
+        lens = [N + (len(m) // K - 1) * hop if len(m) and len(m) % K == 0 else 0 for m in ms]
         if outs is None:
             outs = [np.empty(max(L, 1), dtype=np.float64) for L in lens]
         elif len(outs) != n or any(o.dtype != np.float64 or o.ndim != 1 or len(o) < L or not o.flags.c_contiguous for o, L in zip(outs, lens)):
@@ -187,14 +190,18 @@ class Engine:
                 if x is not None and x.shape != (L,):
                     raise ValueError("x0 length mismatch")
         dpp = ctypes.POINTER(c_double_p)
-        mp = (c_double_p * n)(*[m.ctypes.data_as(c_double_p) for m in ms])
-        op = (c_double_p * n)(*[o.ctypes.data_as(c_double_p) for o in outs])
-        xp = None if xs is None else (c_double_p * n)(*[None if x is None else x.ctypes.data_as(c_double_p) for x in xs])
-        sp = None if seeds is None else (ctypes.c_uint64 * n)(*[int(s) & (2 ** 64 - 1) for s in seeds])
-        npairs = (ctypes.c_size_t * n)(*[len(m) for m in ms])
-        caps = (ctypes.c_size_t * n)(*[len(o) for o in outs])
-        check(_lib.lib().gomel_from_mel_batch(self._h, n, ctypes.cast(mp, dpp), npairs, None if xp is None else ctypes.cast(xp, dpp), sp,
-                                              ctypes.cast(op, dpp), caps), "gomel_from_mel_batch")
+
+        def ptrs(arrs):   # one uintp array instead of n ctypes pointer objects (a 256-utterance call spent ~1 ms building those)
+            return np.array([0 if a is None else a.__array_interface__["data"][0] for a in arrs], dtype=np.uintp)
+        mp, op = ptrs(ms), ptrs(outs)
+        xp = None if xs is None else ptrs(xs)
+        sp = None if seeds is None else np.array([int(s) & (2 ** 64 - 1) for s in seeds], dtype=np.uint64)
+        npairs = np.array([len(m) for m in ms], dtype=np.uintp)
+        caps = np.array([len(o) for o in outs], dtype=np.uintp)
+        as_p = lambda a, t: a.ctypes.data_as(t)
+        check(_lib.lib().gomel_from_mel_batch(self._h, n, as_p(mp, dpp), as_p(npairs, ctypes.POINTER(ctypes.c_size_t)), None if xp is None else as_p(xp, dpp),
+                                              None if sp is None else as_p(sp, ctypes.POINTER(ctypes.c_uint64)), as_p(op, dpp),
+                                              as_p(caps, ctypes.POINTER(ctypes.c_size_t))), "gomel_from_mel_batch")
         return [o[:L] for o, L in zip(outs, lens)]
 
     def target_magnitudes(self, mel_pairs):

@@ -351,10 +351,13 @@ def main():
 
     # device-side figures (outside the timed region): one BLOCK resident in HBM
     res_fps, tm = resident(engine, fields, min(n_utt, BLOCK), frames, first, max(3, min(args.steps, 10)))
-    # inside the timed region the library cuts a call into chunks (min(16, frames / 12288), gomel_hip.hip): the same kernel at the chunk's size
+    # inside the timed region the library cuts a call into chunks (from_mel_batch_guarded in gomel_hip.hip: m = frames / 12288 full
+    # chunks' worth at Resolut 4096, / 32768 below, cut half : full x (m-1) : half): the same kernel at a full chunk's size
     nb = min(n_utt, BLOCK)
-    n_chunks = min(16, max(1, nb * frames // 12288), nb)
-    tm_chunk = resident(engine, fields, -(-nb // n_chunks), frames, first, 3)[1] if n_chunks > 1 else tm
+    full = 12288 if fields["Resolut"] >= 4096 else 32768
+    m_full = min(16, max(1, nb * frames // full))
+    n_chunks = 1 if nb * frames < full else min(m_full + 1, nb)
+    tm_chunk = resident(engine, fields, max(1, round(nb / m_full)), frames, first, 3)[1] if n_chunks > 1 else tm
 
     side = rank == 0 and world == 1 and not args.no_single           # side measurements: N = 1 only
     single = pageable = cfg1 = None
@@ -405,7 +408,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "launch": "one launch over the whole %d-utterance batch (the configuration as BASELINE names it), HIP events on the library's stream in this process" % min(n_utt, BLOCK),
-                         "timed_region_launches": {"what": "the same kernel at the size the host-to-host call launches it (%d chunks per call, copy/compute overlap)" % n_chunks,
+                         "timed_region_launches": {"what": "the same kernel at the size of a full chunk of the host-to-host call (%d chunks per call, first and last half-size; copy/compute overlap)" % n_chunks,
                                                    "frames_per_launch": tm_chunk["frames"], "launch_ms": tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]),
                                                    "frac": tm_chunk["frames"] * algorithmic_bytes_per_frame_iter(N, hop) / (tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "whole_job_frac_resident": res_fps * per_frame_bytes / 1e9 / HBM_PEAK_GBS,

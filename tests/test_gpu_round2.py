@@ -320,6 +320,34 @@ def test_fused_fp64_kernel_matches_the_oracle(oracle, N, K, fmax, SH):
         assert rms(g - want) < 1e-9 * max(1.0, rms(want)), (N, SH, len(mm) // K, rms(g - want))
 
 
+def test_uneven_chunk_plans_recycle_buffers_correctly(oracle, monkeypatch):
+    """The pipeline's chunks are not equal (half-size first and last by default; any plan through GOMEL_CHUNK_SHARES): buffers of
+    a finished chunk serve a later, differently sized one while two other chunks are in flight.  Ten uneven chunks, twice, against
+    the default plan and against one resident batch."""
+    import gomel_amd
+    fields = dict(S, GriffinLimIterations=3)
+    m = mel_obj(fields)
+    e = m.engine()
+    rng = np.random.default_rng(5)
+    frames = rng.integers(20, 400, size=120).tolist()
+    mels = [oracle.random_logmel(f, 80, seed=900 + i) for i, f in enumerate(frames)]
+    seeds = list(range(120))
+    base = e.from_mel_batch(mels, None, seeds)
+    for plan in ("1,3,1,2,1,1,2,1,1,1", "5,1,1,1,1,1,5", "1,1"):
+        monkeypatch.setenv("GOMEL_CHUNK_SHARES", plan)
+        got = e.from_mel_batch(mels, None, seeds)
+        again = e.from_mel_batch(mels, None, seeds)
+        monkeypatch.delenv("GOMEL_CHUNK_SHARES")
+        assert all(np.array_equal(a, b) for a, b in zip(got, again)), plan
+        assert all(a.shape == b.shape and rms(a - b) < 1e-5 for a, b in zip(got, base)), plan      # other segmentation: rounding only
+    b = gomel_amd.Batch(e, [len(mm) for mm in mels])
+    b.upload(mels, None, seeds)
+    b.run()
+    for a, r in zip(base, b.download()):
+        assert rms(a - r) < 1e-5
+    b.close()
+
+
 def test_chunked_pipeline_on_a_ragged_batch(oracle):
     """gomel_from_mel_batch cuts big calls into chunks that cycle through three sets of device buffers (upload c+1 / compute c /
     download c-1): a ragged 300-utterance batch (3 ... 700 frames, 8+ chunks), explicit x0 for some utterances, against the same

@@ -656,6 +656,139 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
 #endif
 }
 
+// The same persistent kernel in fp64 (64-bit mode, the mode that agrees with the reference's arithmetic on every input): one stream
+// per frame, three exchange buffers of doubles, the same sentinel protocol.  A lane's unit of exchange is one pair of doubles
+// (16 bytes: row j, pair t), so no quad packing; the sums run in ascending frame order, i.e. are k_ola<double>'s, and the result
+// equals the fp64 generic pair's bit for bit.  Registers go to the FFT (fp64 temporaries) and to the gather (8 rows x 4 covering
+// frames of pairs in flight, two passes over the rows): tables, magnitudes and the frame's own previous output are re-read.
+// Needs hop even (a pair never straddles a hop) and at most kPersistMaxNb neighbours on each side.
+typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
+// A double is "not stored yet" when its HIGH word is all ones (a NaN no arithmetic produces: results carry 0x7ff8.../0xfff8...).  The low
+// word cannot serve as well: 2^-32 of all finite doubles end in 32 one-bits, which over the 84 M values of one utterance would stall
+// a call in fifty.  So this relies on an aligned 8-byte half of a 16-byte store never being torn (observed for 8-byte granules,
+// MI355X_MICROARCH.md visibility section; a store's 16 bytes lie in one 128-byte line).
+GL_DEV bool persist_fresh_d(v4u q) { return q.y != kPersistSentinel && q.w != kPersistSentinel; }
+
+template <int N>
+__global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
+                                                        const double* __restrict__ mag, const double* __restrict__ nyq, double* yw,
+                                                        unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = 128 / T, DEPTH = 4;
+    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < n_frames;
+    if (!live) frame = n_frames - 1;
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    auto sync = [] { __syncthreads(); };
+    const UttDesc u = utts[frame_utt[frame]];
+    const int f = (int)(frame - u.fbase), F = u.frames;
+    const int nb = (N - 1) / hop;
+    const v2d* w2 = reinterpret_cast<const v2d*>(tb.windowd);
+    int geo[16];   // per row j (pair t + T j, samples 2 (t + T j), +1): k0 | cnt << 20 (covering frames k0 .. k0 + cnt - 1)
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const unsigned n = (unsigned)f * (unsigned)hop + 2u * (unsigned)(t + T * j);
+        const unsigned a = n >= (unsigned)N ? (n - (unsigned)N) / (unsigned)hop + 1u : 0u;
+        unsigned b = n / (unsigned)hop;
+        if (b > (unsigned)(F - 1)) b = (unsigned)(F - 1);
+        geo[j] = (int)(a | (b - a + 1u) << 20);
+    }
+    // yw = three buffers back to back, [3][n_frames][N] doubles (< 2^32 bytes: host check)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(yw, 0, 0xffffffff, 0x00020000);
+    const unsigned buf_bytes = (unsigned)(n_frames * N) * 8u;
+    const unsigned my_off = (unsigned)(frame * N + 2 * t) * 8u;                                  // + 2 T j doubles per row
+    const unsigned base_off = (unsigned)(u.fbase * N + (int64_t)f * hop + 2 * t) * 8u;           // frame k0's copy of row 0's pair; + (N - hop) doubles per covering frame
+    const unsigned kstep = (unsigned)(N - hop) * 8u;
+    const v4u sentinel = v4u{kPersistSentinel, kPersistSentinel, kPersistSentinel, kPersistSentinel};
+    bool dead = false;
+    int cur = 0, prev = 2, next = 1;
+    for (int it = 0; it < iters; it++) {
+        v2d v[16];
+        int tl = t;   // opaque copy of the lane index: keeps the compiler from hoisting (and spilling) this iteration's table addresses
+        asm volatile("" : "+v"(tl));
+        if (it == 0) {
+            typedef v2d v2d_a8 __attribute__((aligned(8)));
+            const v2d_a8* xs = reinterpret_cast<const v2d_a8*>(x0 + u.xoff + (int64_t)f * hop);
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = xs[t + T * j];
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {   // rows 0..7, then 8..15: 32 pairs of 16 B in flight per lane
+                v2d acc[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) acc[jj] = v2d{0.0, 0.0};
+                for (int dk = 0; dk <= nb; dk += DEPTH) {
+                    v4u a[8][DEPTH];
+                    unsigned todo = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+                        for (int q = 0; q < DEPTH; q++) {
+                            a[jj][q] = v4u{0u, 0u, 0u, 0u};
+                            if (dk + q < (geo[8 * half + jj] >> 20 & 31)) todo |= 1u << (DEPTH * jj + q);
+                        }
+                    if (dead) todo = 0;
+                    unsigned long long t0 = 0;
+                    for (unsigned spins = 0;; spins++) {
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+                            for (int q = 0; q < DEPTH; q++)
+                                if (todo & (1u << (DEPTH * jj + q)))
+                                    a[jj][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_off + (unsigned)(2 * T * (8 * half + jj)) * 8u + (unsigned)((geo[8 * half + jj] & 0xfffff) + dk + q) * kstep,
+                                                                                     (unsigned)prev * buf_bytes, 16);   // aux 16 = sc1
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+                            for (int q = 0; q < DEPTH; q++)
+                                if ((todo & (1u << (DEPTH * jj + q))) && persist_fresh_d(a[jj][q])) todo &= ~(1u << (DEPTH * jj + q));
+                        if (!__any(todo != 0u)) break;
+                        if (t0 == 0) t0 = wall_clock64();
+                        const bool other = (spins & 15u) == 15u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                        if (other || wall_clock64() - t0 > spin_ticks) {
+                            if (!other && (threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            dead = true;
+                            break;
+                        }
+                        for (int d = 0; d < retry_nap; d++) __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+                        for (int q = 0; q < DEPTH; q++) acc[jj] += __builtin_bit_cast(v2d, a[jj][q]);   // absent frames add the zeros a[][] started as
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) v[8 * half + jj] = acc[jj];
+            }
+        }
+        if (live) {   // the slot iteration it + 1 will fill (k_gl_persist's argument)
+#pragma unroll
+            for (int j = 0; j < 16; j++) __builtin_amdgcn_raw_buffer_store_b128(sentinel, rs, my_off + (unsigned)(2 * T * j) * 8u, (unsigned)next * buf_bytes, 16);
+        }
+        MagRegsD mr;
+        v2d wn[8];
+        load_mags<G>(mr, tl, mag + frame * G::C, nyq + frame);
+        load_wn<G>(wn, tl, tb.wnd);
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] *= w2[tl + T * j];
+        fft_forward<G>(v, my, tl, tw, sync);
+        spectral_apply<G>(v, t, mr, wn);
+        asm volatile("" : "+v"(tl));
+        fft_inverse<G>(v, my, tl, tw, sync);
+        asm volatile("" : "+v"(tl));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sentinel stores are through before any fresh pair goes out
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const v2d y = v[j] * w2[tl + T * j];
+            if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, y), rs, my_off + (unsigned)(2 * T * j) * 8u, (unsigned)cur * buf_bytes, 16);
+        }
+        prev = cur; cur = next; next = next == 2 ? 0 : next + 1;
+    }
+}
+
 template <int N, int SH>
 __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __restrict__ x_in, const float* __restrict__ tail_in,
                                                      float* __restrict__ x_out, float* __restrict__ tail_out,

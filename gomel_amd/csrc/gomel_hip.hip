@@ -111,7 +111,7 @@ struct gomel_handle {
     bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
     // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
     // slab of timeout words (one per live batch: the kernel's *err comes down with the waveforms, no extra round trip)
-    int persist_census[2] = {-1, -1};   // workgroups of k_gl_persist<Resolut, 1 | 2> the device holds at once (-1: not asked yet)
+    int persist_census[3] = {-1, -1, -1};   // workgroups of k_gl_persist<Resolut, 1 | 2> / k_gl_persist_d<Resolut> the device holds at once (-1: not asked yet)
     bool persist_off = false;     // a launch timed out once (another context held the CUs): per-iteration kernels from then on
     unsigned* err_slab = nullptr; // [kErrSlots] pinned
     std::vector<int> err_free;
@@ -546,12 +546,22 @@ template <int N, int OCC> static int persist_census_n(int device) {
     }
     return per_cu * cus;
 }
-static int persist_census(gomel_handle* h, int occ) {   // caller holds a DeviceGuard
+template <int N> static int persist_census_d(int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist_d<N>, 128, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu * cus;
+}
+static int persist_census(gomel_handle* h, int occ) {   // occ 1 / 2: the fp32 kernel's builds; 3: the fp64 kernel.  Caller holds a DeviceGuard
     int& c = h->persist_census[occ - 1];
     if (c < 0) {
         int n = 0;
         if (occ == 1) { GOMEL_DISPATCH_N(h->cfg.resolut, n = (persist_census_n<NN, 1>(h->device))); }
-        else { GOMEL_DISPATCH_N(h->cfg.resolut, n = (persist_census_n<NN, 2>(h->device))); }
+        else if (occ == 2) { GOMEL_DISPATCH_N(h->cfg.resolut, n = (persist_census_n<NN, 2>(h->device))); }
+        else { GOMEL_DISPATCH_N(h->cfg.resolut, n = persist_census_d<NN>(h->device)); }
         c = n;
     }
     return c;
@@ -723,7 +733,17 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             int curd = 0;
             const int64_t spb = h->generic ? 1 : 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
             if (b->fast) HIPCHK(hipMemsetAsync(b->d_taild[0], 0, b->segs.size() * (size_t)(N - c.window) * 8, s));
-            for (int it = 0; it < I; it++) {
+            if (b->persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
+                const size_t buf_doubles = (size_t)b->total_frames * N;
+                HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
+                HIPCHK(hipMemsetAsync(b->d_ywd, 0xff, buf_doubles * 8, s));
+                if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
+                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
+                                                       b->d_ywd, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
+                if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
+                hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd + (size_t)((I - 1) % 3) * buf_doubles, out64, N, c.window);
+            }
+            for (int it = 0; it < I && !b->persist; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
                 if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
                 if (h->generic)
@@ -738,7 +758,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
             if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
-            HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
+            if (!b->persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
             if (b->fast) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
@@ -1061,14 +1081,17 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms
     // generic, hop 128 1.25 against 1.14 -- so the library picks the kernel down to hop = N/8 only; gomel_set_path(h, 3) still runs it)
     const bool persist_pays = (N - 1) / hop <= kPersistAutoNb || h->path_mode == 3;
-    if (!b->precise && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && persist_pays && I >= 2) {
+    if (!h->generic && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && persist_pays && I >= 2) {
         const int spw = 128 / (N / 32);                                  // streams (frames) per workgroup
         const int64_t n_wg = (b->total_frames + spw - 1) / spw;
         int max_frames = 0;
         for (const UttDesc& d : b->utts) max_frames = std::max(max_frames, d.frames);
-        if (!h->persist_off && h->err_slab && !h->err_free.empty() && n_wg <= persist_census(h, 2) &&
-            b->total_frames * (int64_t)N < ((int64_t)1 << 28) && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20)) {
+        const bool room = !h->persist_off && h->err_slab && !h->err_free.empty() && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20);
+        if (room && !b->precise && n_wg <= persist_census(h, 2) && b->total_frames * (int64_t)N < ((int64_t)1 << 28))
             b->persist = n_wg <= persist_census(h, 1) ? 1 : 2;   // = the kernel's OCC: one wave per SIMD while the batch fits that way
+        else if (room && b->precise && n_wg <= persist_census(h, 3) && b->total_frames * (int64_t)N < ((int64_t)1 << 27))
+            b->persist = 3;                                       // 64-bit mode: k_gl_persist_d (three buffers of doubles: < 2^32 bytes)
+        if (b->persist) {
             b->n_wg = (int)n_wg;
             b->err_slot = h->err_free.back(); h->err_free.pop_back();
         }
@@ -1097,8 +1120,13 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             for (int i = 0; i < 2; i++)
                 if (!rc && hipMemsetAsync(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8, ist) != hipSuccess) rc = GOMEL_ERR_HIP;
         } else {
-            alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8);
+            alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8 * (b->persist ? 3 : 1));
             alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+            if (b->persist) {
+                b->ctl_bytes = 16;
+                alloc((void**)&b->d_ctl, b->ctl_bytes);
+                alloc((void**)&b->d_frame_utt, (size_t)b->total_frames * 4);
+            }
         }
     } else if (I > 0) {
         alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);

@@ -13,12 +13,14 @@ pytestmark = pytest.mark.gpu
 PERSIST, GENERIC = 3, 1
 
 
-def engine(N, hop, K, iters, path, fmax=8000.0):
+def engine(N, hop, K, iters, path, fmax=8000.0, bits=32):
     import gomel_amd
     m = gomel_amd.NewMel()
     m.NumMels, m.MelFmax, m.Window, m.Resolut, m.GriffinLimIterations = K, fmax, hop, N, iters
     e = m.engine()
     e.set_path(path)
+    if bits != 32:
+        e.set_precision(bits)
     return m, e
 
 
@@ -187,4 +189,43 @@ def test_repeated_runs_and_a_busy_chip_never_change_a_bit(oracle):
     finally:
         stop.set()
         th.join()
+    b.close(); e.close()
+
+
+@pytest.mark.parametrize("N,hop,K", [(4096, 1280, 192), (4096, 512, 96), (4096, 4100, 96), (2048, 256, 160), (2048, 516, 80), (1024, 256, 80),
+                                      (1024, 64, 80), (512, 160, 64), (256, 80, 40), (256, 36, 40)])
+def test_fp64_persistent_equals_fp64_generic_bit_for_bit(oracle, N, hop, K):
+    """64-bit mode has its own persistent kernel (k_gl_persist_d: pairs of doubles, the same sentinel protocol)."""
+    frames = [41, 1, 2, 13, 30]
+    mels = logmels(oracle, frames, K, seed0=7)
+    seeds = list(range(len(frames)))
+    for iters in (2, 6):
+        mp, ep = engine(N, hop, K, iters, PERSIST, bits=64)
+        outp, tmp = run(ep, mels, seeds)
+        mg, eg = engine(N, hop, K, iters, GENERIC, bits=64)
+        outg, tmg = run(eg, mels, seeds)
+        assert tmp["fast_path"] == 2 and tmp["iter_launches"] == 1 and tmg["fast_path"] == 0
+        for a, b in zip(outp, outg):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        ep.close(); eg.close()
+
+
+def test_fp64_single_utterance_matches_the_oracle_to_rounding(oracle):
+    """BASELINE configs[1] in 64-bit mode, the library's own path choice: 1e-12 from the fp64 restatement after 60 iterations is
+    out of reach (the instabilities of DESIGN.md section 2 amplify last-bit differences too), after 8 it is not."""
+    N, hop, K, F, I = 4096, 1280, 192, 342, 8
+    mel = oracle.random_logmel(F, K, seed=21)
+    m, e = engine(N, hop, K, I, 0, fmax=16000.0, bits=64)
+    (out,), tm = run(e, [mel], [4])
+    assert tm["fast_path"] == 2 and tm["dom_kernel"] == "k_gl_persist"
+    cfg = oracle.MelConfig(NumMels=K, MelFmax=16000.0, Window=hop, Resolut=N, GriffinLimIterations=I)
+    want = oracle.from_mel(cfg, mel.copy(), oracle.x0_splitmix(4, len(out)))
+    assert float(np.sqrt(np.mean((out - want) ** 2))) < 1e-11
+    b = None
+    import gomel_amd
+    b = gomel_amd.Batch(e, [F * K])
+    b.upload([mel], None, [4])
+    for rep in range(40):                       # repeated runs over the same buffers: a stale read would show
+        b.run()
+        assert np.array_equal(b.download()[0], out), rep
     b.close(); e.close()

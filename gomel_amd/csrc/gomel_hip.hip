@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -499,11 +500,13 @@ struct gomel_batch {
     int persist = 0;
     int n_wg = 0;
     int err_slot = -1;
+    int persist_units = 0;     // share of the device this batch's queued persistent launch is accounted with (persist_take)
     int32_t* d_frame_utt = nullptr;
     unsigned* d_ctl = nullptr;
     size_t ctl_bytes = 0;
 };
 
+static void persist_release(gomel_batch* b);
 static void batch_free(gomel_batch* b) {
     if (!b) return;
     DeviceGuard dg(b->h->device);
@@ -511,6 +514,7 @@ static void batch_free(gomel_batch* b) {
                     b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd,
                     b->d_frame_utt, b->d_ctl};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
+    persist_release(b);
     if (b->err_slot >= 0) b->h->err_free.push_back(b->err_slot);
     for (auto& e : b->ev) if (e) hipEventDestroy(e);
     for (auto& e : b->dom_ev) if (e) hipEventDestroy(e);
@@ -683,6 +687,27 @@ template <int N> static void launch_frames(gomel_batch* b, const float* x) {
 
 static int batch_run_impl(gomel_batch* b, gomel_timing* tm);
 
+// Persistent launches of DIFFERENT handles on one device must not overlap beyond the chip's capacity: each needs all its
+// workgroups resident, and two half-resident launches would wait for each other until both give up.  Launches are therefore
+// accounted in 1/1024ths of the device (n_wg against the census of the build in use) from the moment they are queued until the
+// host has seen them finish (sync / download / destroy); a run that finds no room goes through the per-iteration kernels instead
+// (same bits).  Within one process only: another process on the same GPU is what the kernel's own time limit is for.
+static std::atomic<int> g_persist_units[64];
+static int persist_units(gomel_batch* b) {
+    const int census = std::max(1, persist_census(b->h, b->persist));
+    return (int)std::min<int64_t>(1024, ((int64_t)b->n_wg * 1024 + census - 1) / census);
+}
+static bool persist_take(gomel_batch* b) {   // caller holds h->mu and a DeviceGuard
+    if (b->persist_units) return true;        // an earlier run of this batch is still accounted: same stream, it runs behind it
+    const int u = persist_units(b), dev = b->h->device & 63;
+    if (g_persist_units[dev].fetch_add(u) + u > 1024) { g_persist_units[dev].fetch_sub(u); return false; }
+    b->persist_units = u;
+    return true;
+}
+static void persist_release(gomel_batch* b) {   // the batch's launches are known to have finished (or never ran)
+    if (b->persist_units) { g_persist_units[b->h->device & 63].fetch_sub(b->persist_units); b->persist_units = 0; }
+}
+
 // A persistent launch gave up (k_gl_persist: a workgroup waited 20 ms for a neighbour -- some other context held the CUs it
 // needed): nothing of its output is used.  x0 is still in d_x[0] (the kernel only reads it), so the batch is recomputed with the
 // per-iteration kernels, and the handle stops choosing the persistent path.  Caller holds h->mu and has synchronised the stream.
@@ -690,6 +715,7 @@ static int persist_redo(gomel_batch* b, gomel_timing* tm) {
     gomel_handle* h = b->h;
     h->persist_off = true;
     h->err_slab[b->err_slot] = 0;
+    persist_release(b);
     b->persist = 0;
     int rc = batch_run_impl(b, tm);
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
@@ -697,6 +723,7 @@ static int persist_redo(gomel_batch* b, gomel_timing* tm) {
 }
 // after the stream has drained: did the batch's persistent launch complete?
 static int persist_verify(gomel_batch* b) {
+    persist_release(b);
     if (!b->persist || !b->h->err_slab[b->err_slot]) return GOMEL_OK;
     return persist_redo(b, nullptr);
 }
@@ -707,6 +734,8 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     const int N = c.resolut, K = c.num_mels, I = b->iters >= 0 ? b->iters : c.griffin_lim_iterations;
     hipStream_t s = h->stream;
     if (!b->uploaded) return GOMEL_ERR_NULL;
+    // this run's path: the batch's persistent kernel only while the chip has room for it next to the other handles' (persist_take)
+    const int persist = (b->persist && I > 0 && persist_take(b)) ? b->persist : 0;
     if (tm) {
         while ((int)b->dom_ev.size() < 2 * I) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->dom_ev.push_back(e); }
         HIPCHK(hipEventRecord(b->ev[0], s));
@@ -733,7 +762,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             int curd = 0;
             const int64_t spb = h->generic ? 1 : 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
             if (b->fast) HIPCHK(hipMemsetAsync(b->d_taild[0], 0, b->segs.size() * (size_t)(N - c.window) * 8, s));
-            if (b->persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
+            if (persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
                 const size_t buf_doubles = (size_t)b->total_frames * N;
                 HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
                 HIPCHK(hipMemsetAsync(b->d_ywd, 0xff, buf_doubles * 8, s));
@@ -743,7 +772,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
                 hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd + (size_t)((I - 1) % 3) * buf_doubles, out64, N, c.window);
             }
-            for (int it = 0; it < I && !b->persist; it++) {
+            for (int it = 0; it < I && !persist; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
                 if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
                 if (h->generic)
@@ -758,7 +787,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
             if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
-            if (!b->persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
+            if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
             if (b->fast) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
@@ -770,7 +799,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         int cur = 0;
         const size_t tail_bytes = b->segs.size() * (size_t)(N - c.window) * 4;
         if (b->fast) HIPCHK(hipMemsetAsync(b->d_tail[0], 0, tail_bytes, s));  // x0 has no tail contributions
-        if (b->persist) {   // all I iterations in one launch; x_I = overlap-add of the last iteration's frames
+        if (persist) {   // all I iterations in one launch; x_I = overlap-add of the last iteration's frames
             const size_t buf_floats = (size_t)b->total_frames * N;
             HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
             // buf[0] starts as "not stored yet" (kPersistSentinel); the streams themselves reset their slots of buf[1] and buf[2] in
@@ -780,7 +809,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
 #define GOMEL_PERSIST_LAUNCH(OCC, DEPTH)                                                                                                                     \
     GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, OCC, DEPTH>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, \
                                            b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt))
-            if (b->persist == 2) { GOMEL_PERSIST_LAUNCH(2, 2); }
+            if (persist == 2) { GOMEL_PERSIST_LAUNCH(2, 2); }
             else { GOMEL_PERSIST_LAUNCH(1, 4); }   // (eight covering frames in flight, for hops below N/4, measured slower than two rounds of four: its registers come out of the tables')
 #undef GOMEL_PERSIST_LAUNCH
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
@@ -788,7 +817,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (b->io32) hipLaunchKernelGGL(k_ola_out<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out32, N, c.window);
             else hipLaunchKernelGGL(k_ola_out<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out64, N, c.window);
         }
-        for (int it = 0; it < I && !b->persist; it++) {
+        for (int it = 0; it < I && !persist; it++) {
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
             if (b->fast) launch_fused(b, cur);
             else { GOMEL_DISPATCH_N(N, launch_frames<NN>(b, b->d_x[cur])); }
@@ -803,7 +832,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                                   hipLaunchKernelGGL((k_spec_writeback<NN, v2f>), dim3((unsigned)((b->total_frames + SPB - 1) / SPB)), dim3(128), 0, s, b->d_x[cur ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt); });
         }
         const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
-        if (b->persist) {
+        if (persist) {
             // k_ola_out has written the waveforms
         } else if (b->io32) {
             hipLaunchKernelGGL(k_finalize<float>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out32, b->total_len);
@@ -814,22 +843,23 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         }
         }
     }
-    if (b->persist && I > 0) HIPCHK(hipMemcpyAsync(h->err_slab + b->err_slot, b->d_ctl, 4, hipMemcpyDeviceToHost, s));
+    if (persist && I > 0) HIPCHK(hipMemcpyAsync(h->err_slab + b->err_slot, b->d_ctl, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
     if (tm) {
         HIPCHK(hipEventRecord(b->ev[3], s));
         HIPCHK(hipEventSynchronize(b->ev[3]));
-        if (b->persist && I > 0 && h->err_slab[b->err_slot]) return persist_redo(b, tm);
+        if (persist) persist_release(b);   // seen to finish
+        if (persist && I > 0 && h->err_slab[b->err_slot]) return persist_redo(b, tm);
         HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
         HIPCHK(hipEventElapsedTime(&tm->iter_ms, b->ev[1], b->ev[2]));
         tm->dom_ms = 0.f;
-        for (int it = 0; it < (b->persist ? std::min(I, 1) : I); it++) {
+        for (int it = 0; it < (persist ? std::min(I, 1) : I); it++) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, b->dom_ev[2 * it], b->dom_ev[2 * it + 1]));
             tm->dom_ms += ms;
         }
-        tm->iter_launches = b->persist ? std::min(I, 1) : I;
-        tm->fast_path = b->persist ? 2 : b->fast;
+        tm->iter_launches = persist ? std::min(I, 1) : I;
+        tm->fast_path = persist ? 2 : b->fast;
         tm->frames = b->total_frames;
     }
     return GOMEL_OK;

@@ -229,3 +229,42 @@ def test_fp64_single_utterance_matches_the_oracle_to_rounding(oracle):
         b.run()
         assert np.array_equal(b.download()[0], out), rep
     b.close(); e.close()
+
+
+def test_concurrent_persistent_launches_of_several_handles_share_the_chip(oracle):
+    """Each persistent launch needs all its workgroups resident; two of different handles, half resident each, would wait for one
+    another until both give up.  The library accounts queued persistent launches per device and sends a run that finds no room
+    through the generic kernels: four threads, four handles, 342-frame utterances (two fit the chip together, four do not) --
+    every result exact, and afterwards every handle still takes the persistent path (nobody timed out)."""
+    import threading
+    import gomel_amd
+    N, hop, K, I = 4096, 1280, 192, 10
+    mel = oracle.random_logmel(342, K, seed=33)
+    mg, eg = engine(N, hop, K, I, GENERIC, fmax=16000.0)
+    (ref,), _ = run(eg, [mel], [8])
+    eg.close()
+    engines = [engine(N, hop, K, I, 0, fmax=16000.0)[1] for _ in range(4)]
+    errors, paths = [], [set() for _ in engines]
+
+    def work(i):
+        try:
+            b = gomel_amd.Batch(engines[i], [342 * K])
+            b.upload([mel], None, [8])
+            for _ in range(60):
+                b.run()                                  # queued, not waited for: launches of the four handles overlap
+                out = b.download()[0]
+                if not np.array_equal(out, ref):
+                    errors.append((i, "mismatch"))
+            paths[i].add(b.run_timed()["fast_path"])
+            b.close()
+        except Exception as ex:                          # noqa: BLE001 -- reported below
+            errors.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors[:3]
+    for e in engines:                                    # alone again: the path is still on
+        (out,), tm = run(e, [mel], [8])
+        assert tm["fast_path"] == 2 and np.array_equal(out, ref)
+        e.close()

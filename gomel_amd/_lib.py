@@ -52,6 +52,7 @@ SYMBOLS = {
                                                 ctypes.POINTER(c_float_p), c_u64_p, ctypes.POINTER(c_float_p), c_size_p]),
     "gomel_from_mel_batch_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p,
                                                   ctypes.POINTER(c_double_p), c_u64_p, ctypes.POINTER(c_double_p), c_size_p]),
+    "gomel_plan_chunks": (ctypes.c_int, [_cfg_p, ctypes.c_size_t, c_size_p, c_size_p, ctypes.c_size_t, c_size_p]),
     "gomel_host_alloc": (_vp, [ctypes.c_size_t]),
     "gomel_host_free": (ctypes.c_int, [_vp]),
     "gomel_host_register": (ctypes.c_int, [_vp, ctypes.c_size_t]),

@@ -1291,32 +1291,19 @@ int gomel_batch_destroy(gomel_batch* b) {
     return GOMEL_OK;
 }
 
-// Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances and pipelined over three
-// streams: chunk c+1's log-mel goes up (up_stream) while chunk c computes (stream) and chunk c-1's waveforms come down
-// (copy_stream); PCIe is full duplex, so with pinned host buffers the wall time is the compute time plus the first upload and
-// the last download.  Caller buffers that are not already pinned (gomel_host_alloc / gomel_host_register) are pinned for the call.
-static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
-                                  const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
-    if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
-    if (n_utt == 0) return GOMEL_ERR_EMPTY;
-    const int K = h->cfg.num_mels;
-    const size_t esz = io32 ? 4 : 8;
+// How a host-to-host call is cut into chunks: bounds[0] = 0 < bounds[1] < ... < bounds[n_chunks] = n_utt (utterance indices).  Host
+// logic only (exported as gomel_plan_chunks, tested without a GPU).  Lengths must already be validated (multiples of NumMels, > 0).
+static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, const size_t* n_pairs) {
+    const int K = cfg.num_mels;
     int64_t total_frames = 0;
-    for (size_t u = 0; u < n_utt; u++) {
-        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
-        if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
-        if (!mel[u] || !out[u]) return GOMEL_ERR_NULL;
-        const size_t L = gomel_out_len(&h->cfg, n_pairs[u]);
-        if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
-        total_frames += (int64_t)(n_pairs[u] / (size_t)K);
-    }
+    for (size_t u = 0; u < n_utt; u++) total_frames += (int64_t)(n_pairs[u] / (size_t)K);
     // Chunk plan (scripts/chunk_plans.sh, 256 x 400 frames host to host): m full-size chunks' worth of frames, cut as
     // half : full x (m-1) : half -- the half-size first chunk starts the GPU sooner, the half-size last one leaves less download
     // exposed at the end (T geometry: 44.3 ms against 45.6 for eight equal chunks, with m = 8).  A full chunk is ~12k frames at
     // Resolut 4096 (half a round of the chip, 85 us per launch) and ~32k below (shorter frames: the same launch time; at the TTS
     // geometry three full chunks' worth, 13.5 ms, against 16.1 for eight equal chunks).  More, smaller chunks pay launch overhead and
     // per-segment prologues; fewer expose more of the first upload and the last download.
-    const int64_t kMinChunkFrames = h->cfg.resolut >= 4096 ? 12288 : 32768;
+    const int64_t kMinChunkFrames = cfg.resolut >= 4096 ? 12288 : 32768;
     const int m_full = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
     int n_chunks = total_frames < kMinChunkFrames ? 1 : m_full + 1;
     std::vector<double> shares;   // relative chunk sizes
@@ -1339,7 +1326,7 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
         // boundary is therefore moved by up to two utterances to where the chunk it closes fills its rounds best.
         std::vector<int64_t> pre(n_utt + 1, 0);
         for (size_t u = 0; u < n_utt; u++) pre[u + 1] = pre[u] + (int64_t)(n_pairs[u] / (size_t)K);
-        const int64_t round0 = fused_applicable(h->cfg) ? (int64_t)512 * (kFusedThreads / (h->cfg.resolut / 32)) : 0;
+        const int64_t round0 = fused_applicable(cfg) ? (int64_t)512 * (kFusedThreads / (cfg.resolut / 32)) : 0;
         auto fill = [&](int64_t F) {   // fraction of the launch's stream-time that does work (plan_segments' rounds rule)
             if (round0 == 0 || F <= 0) return 1.0;
             const int64_t slots = std::max<int64_t>(1, (F + 14 * round0) / (28 * round0)) * round0;
@@ -1371,6 +1358,30 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
         for (size_t i = 1; i < bounds.size(); i++) if (bounds[i] <= bounds[i - 1] || bounds[i] > n_utt) { bounds.assign({0, n_utt}); break; }
         n_chunks = (int)bounds.size() - 1;
     }
+    return bounds;
+}
+
+// Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances and pipelined over three
+// streams: chunk c+1's log-mel goes up (up_stream) while chunk c computes (stream) and chunk c-1's waveforms come down
+// (copy_stream); PCIe is full duplex, so with pinned host buffers the wall time is the compute time plus the first upload and
+// the last download.  Caller buffers that are not already pinned (gomel_host_alloc / gomel_host_register) are pinned for the call.
+static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
+                                  const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
+    if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
+    if (n_utt == 0) return GOMEL_ERR_EMPTY;
+    const int K = h->cfg.num_mels;
+    const size_t esz = io32 ? 4 : 8;
+    int64_t total_frames = 0;
+    for (size_t u = 0; u < n_utt; u++) {
+        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
+        if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
+        if (!mel[u] || !out[u]) return GOMEL_ERR_NULL;
+        const size_t L = gomel_out_len(&h->cfg, n_pairs[u]);
+        if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
+        total_frames += (int64_t)(n_pairs[u] / (size_t)K);
+    }
+    std::vector<size_t> bounds = plan_chunks(h->cfg, n_utt, n_pairs);
+    int n_chunks = (int)bounds.size() - 1;
     struct ChunkList {
         std::vector<gomel_batch*> v;
         ~ChunkList() { for (gomel_batch* b : v) if (b) gomel_batch_destroy(b); }
@@ -1780,6 +1791,23 @@ int gomel_debug_stamps(unsigned long long* out21, int clear) {
 #endif
 
 // ---- host memory helpers: pinned buffers a bulk caller reuses across calls (no per-call hipHostRegister)
+int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks) {
+    if (!cfg || !n_pairs || !bounds || !n_chunks) return GOMEL_ERR_NULL;
+    if (n_utt == 0) return GOMEL_ERR_EMPTY;
+    if (cfg->num_mels <= 0 || cfg->window <= 0 || cfg->resolut < 4) return GOMEL_ERR_BAD_CONFIG;
+    for (size_t u = 0; u < n_utt; u++) {
+        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
+        if (n_pairs[u] % (size_t)cfg->num_mels) return GOMEL_ERR_BAD_LENGTH;
+    }
+    GOMEL_TRY
+    const std::vector<size_t> b = plan_chunks(*cfg, n_utt, n_pairs);
+    if (b.size() > cap) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    for (size_t i = 0; i < b.size(); i++) bounds[i] = b[i];
+    *n_chunks = b.size() - 1;
+    return GOMEL_OK;
+    GOMEL_CATCH
+}
+
 void* gomel_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

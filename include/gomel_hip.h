@@ -159,6 +159,13 @@ int gomel_host_free(void* p);
 int gomel_host_register(void* p, size_t bytes);
 int gomel_host_unregister(void* p);
 
+/* How gomel_from_mel_batch / _f32 will cut a call with these utterance lengths into the chunks it pipelines (upload c+1 | compute
+ * c | download c-1): writes *n_chunks + 1 utterance indices 0 = bounds[0] < ... < bounds[*n_chunks] = n_utt.  Host logic only (no
+ * device needed); bounds needs room for at most 66 entries (cap = its capacity).  The plan: half-size first and last chunks, full
+ * chunks of ~12k frames at Resolut 4096 / ~32k below, boundaries moved by up to two utterances to where a chunk fills the fused
+ * kernel's rounds; GOMEL_CHUNKS / GOMEL_CHUNK_SHARES override it. */
+int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks);
+
 /* The same work split so that inputs can be resident in HBM before the clock starts (bench / pipelines):
  * create (plan + allocate) -> upload (H2D of log-mel and x0) -> run (all device work, asynchronous on the
  * handle's stream) -> download (D2H of the waveforms, synchronises). */

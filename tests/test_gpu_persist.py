@@ -268,3 +268,23 @@ def test_concurrent_persistent_launches_of_several_handles_share_the_chip(oracle
         (out,), tm = run(e, [mel], [8])
         assert tm["fast_path"] == 2 and np.array_equal(out, ref)
         e.close()
+
+
+@pytest.mark.parametrize("bits,frames", [(32, [342]), (32, [400, 300]), (64, [342])])
+def test_timeout_fallback_on_every_build_and_entry_point(oracle, monkeypatch, bits, frames):
+    """The forced timeout (GOMEL_PERSIST_TICKS=0) through the one-wave-per-SIMD build, the 256-VGPR build (700 frames) and the fp64
+    kernel, via the resident batch API and via the host-to-host call: always the generic kernels' bits."""
+    N, hop, K, I = 4096, 1280, 192, 6
+    mels = logmels(oracle, frames, K, seed0=50)
+    seeds = list(range(len(frames)))
+    mg, eg = engine(N, hop, K, I, GENERIC, fmax=16000.0, bits=bits)
+    ref, _ = run(eg, mels, seeds)
+    eg.close()
+    monkeypatch.setenv("GOMEL_PERSIST_TICKS", "0")
+    m, e = engine(N, hop, K, I, 0, fmax=16000.0, bits=bits)
+    monkeypatch.delenv("GOMEL_PERSIST_TICKS")
+    got = e.from_mel_batch(mels, None, seeds)                 # host-to-host entry point: runs, verifies, recomputes if need be
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    out, tm = run(e, mels, seeds)                             # resident API afterwards (persistent path possibly switched off by now)
+    assert all(np.array_equal(a, b) for a, b in zip(out, ref)) and tm["fast_path"] in (0, 2)
+    e.close()

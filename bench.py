@@ -75,7 +75,7 @@ def build_engine(fields, device, tables=None):
     return gomel_amd.Engine(m._config(), tables=tables)
 
 
-PATHS = ("generic", "fused", "persistent")      # gomel_timing.fast_path
+PATHS = ("generic", "fused", "persistent", "fused")      # gomel_timing.fast_path (3 = the fused kernel's any-hop form)
 
 
 def committed_traffic(workload, fast_path):

@@ -1020,6 +1020,170 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #endif
 }
 
+// =============================================================================================== fused path, any even hop
+// k_gl_fused covers hop = SH * N/16 because there moving to the next frame is a shift by whole register rows.  For every other
+// (even) hop the same sliding-window scheme works with ONE more idea: rows are just the linear pair index i = t + T j cut into 16
+// pieces, so a shift by hop/2 pairs is "write the 16 rows to the stream's LDS area, read them back hop/2 slots further".  Per
+// frame that is two extra LDS passes -- the input window before the forward FFT (its registers then already hold the next
+// frame's window, and the loads of its hop new samples fly during the FFTs, exactly as in k_gl_fused), the overlap-add
+// accumulator after the inverse -- which a mock measured at +8 % of the fused kernel's time, against the 2.3x of the generic
+// kernels (two launches, the frames' windowed outputs through HBM).  Same segments, same ownership / tail rule as k_gl_fused
+// (a segment owns the samples [s0, s0 + G hop); what its frames add beyond goes to its tail buffer, N - hop floats), runtime hop,
+// one instantiation per N.  Needs: hop even, hop < N, and the planner's G >= ceil((N - hop) / hop) for segments with a successor.
+template <int N>
+__global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* __restrict__ x_in, const float* __restrict__ tail_in,
+                                                         float* __restrict__ x_out, float* __restrict__ tail_out,
+                                                         const SegDesc* __restrict__ segs, int n_segs, int g_max,
+                                                         const float* __restrict__ mag, const float* __restrict__ nyq, int hop, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = kFusedThreads / T, P = N / 2;
+    static_assert(G::LDS_SLOTS >= P, "the stream's exchange area must take one window of pairs");
+    __shared__ v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
+    v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
+    v2f* tw2_l = tw1_l + G::TW1_N;
+    v2f* win_l = tw2_l + G::TW2_N;
+    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1[i];
+    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2[i];
+    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
+    __syncthreads();
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr};   // twiddles from LDS: the registers k_gl_fused keeps them in go to the 16-row accumulator here
+    auto sync = [] {
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    int seg = blockIdx.x * STREAMS + stream;
+    const bool live = seg < n_segs;
+    if (!live) seg = n_segs - 1;
+    SegDesc d = segs[seg];
+    v2f* my = lds + stream * G::LDS_SLOTS;
+    if constexpr (T >= 64) {
+        d.G = __builtin_amdgcn_readfirstlane(d.G);
+        d.has_prev = __builtin_amdgcn_readfirstlane(d.has_prev);
+        d.has_next = __builtin_amdgcn_readfirstlane(d.has_next);
+        seg = __builtin_amdgcn_readfirstlane(seg);
+    }
+    constexpr bool WU = (T >= 64);
+    auto uo = [](long long v) { if constexpr (WU) return uniform_i64(v); else return v; };
+    const int h2 = hop / 2, keep2 = P - h2;                                   // pairs a frame moves on by / shares with its successor
+    const int seg_prev = d.has_prev ? seg - 1 : seg;
+    const v2f* xin_p = reinterpret_cast<const v2f*>(x_in) + uo(d.s0 / 2);     // pair i of frame g: xin_p[g h2 + i]
+    v2f* xout_p = reinterpret_cast<v2f*>(x_out) + uo(d.s0 / 2);
+    const v2f* tprev = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg_prev * keep2);
+    const v2f* town = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg * keep2);
+    v2f* tout = reinterpret_cast<v2f*>(tail_out) + uo((int64_t)seg * keep2);
+    const float* mag_p = mag + uo(d.frame0 * G::C);
+    const float* nyq_p = nyq + uo(d.frame0);
+    const float f_prev = d.has_prev ? 1.f : 0.f, f_next = d.has_next ? 1.f : 0.f;
+    const int owned2 = d.G * h2;   // pairs >= this (segment-relative) belong to the next segment's head: x + tail[seg] there
+    if constexpr (STREAMS > 1) {
+        __shared__ int g_sh[STREAMS];
+        if (t == 0) g_sh[stream] = live ? d.G : 0;
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < STREAMS; i++) m = max(m, g_sh[i]);
+        g_max = m;
+    } else {
+        g_max = d.G;
+    }
+    v2f xin[16], acc[16];
+    const v2f* wl = win_l + t;
+    v2f wn[8];
+    make_wn<G>(wn, t, tb.wn[t]);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {   // the first frame's window: x, the predecessor's tail over its first N - hop samples, the own tail past the owned range
+        const int i = t + T * j;
+        v2f a = xin_p[i];
+        a += tprev[i < keep2 ? i : 0] * (i < keep2 ? f_prev : 0.f);
+        a += town[i >= owned2 ? i - owned2 : 0] * (i >= owned2 ? f_next : 0.f);   // i - owned2 < keep2 because G >= 1
+        xin[j] = a;
+        acc[j] = v2f{0.f, 0.f};
+    }
+    float nyq_all = 0.f;
+    if constexpr (T >= 64) {
+        const int l = threadIdx.x & 63;
+        nyq_all = nyq_p[l < d.G ? l : 0];
+        asm volatile("v_mov_b32 %0, %0" : "+v"(nyq_all));
+    }
+    for (int g = 0; g < g_max; g++) {
+        const bool active = live && g < d.G;
+        const int gg = g < d.G ? g : d.G - 1;
+        MagRaw mraw;
+        load_mag_rows<G>(mraw, t, mag_p + (int64_t)gg * G::C);
+        if constexpr (T >= 64) mraw.nq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq_all), gg));
+        else mraw.nq = nyq_p[gg + (t & 3)];
+        v2f v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = wl[T * j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] *= xin[j];
+        // slide the input window by hop/2 pairs: through LDS for the pairs that stay, from memory for the hop/2 new ones (their
+        // loads are in flight during the FFTs; nothing reads xin again before the next frame)
+        const bool more = g + 1 < d.G;
+        const int base2 = (g + 1) * h2;                                   // segment-relative pair index of the next frame's pair 0
+        const bool any_next = more && d.has_next && base2 + P > owned2;  // ... whose end reaches into the next segment's head
+#pragma unroll
+        for (int j = 0; j < 16; j++) my[t + T * j] = xin[j];
+        sync();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int i = t + T * j;
+            if (T * (j + 1) <= keep2) xin[j] = my[i + h2];                 // whole row stays (wave-uniform test)
+            else if (T * j >= keep2) xin[j] = xin_p[more ? base2 + i : i]; // whole row new (clamped address when there is no next frame)
+            else xin[j] = i < keep2 ? my[i + h2] : xin_p[more ? base2 + i : i];
+        }
+        if (any_next) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = t + T * j, pp = base2 + i;
+                if (T * (j + 1) > keep2) xin[j] += town[(i >= keep2 && pp >= owned2) ? pp - owned2 : 0] * ((i >= keep2 && pp >= owned2) ? 1.f : 0.f);
+            }
+        }
+        sync();   // the exchange area goes to the FFT now
+        fft_forward<G>(v, my, t, tw, sync);
+        {
+            MagRegs mr;
+            finish_mags(mr, mraw, t == 0);
+            spectral_apply<G>(v, t, mr, wn);
+        }
+        fft_inverse<G>(v, my, t, tw, sync);
+        // overlap-add in registers; the first hop/2 pairs are finished by this frame and leave; the rest moves down by hop/2 pairs
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] += v[j] * wl[T * j];
+        if (active) {
+            v2f* xo = xout_p + g * h2;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = t + T * j;
+                if (T * j < h2 && i < h2) xo[i] = acc[j];
+            }
+        }
+        sync();   // the inverse FFT's last reads of the exchange area are done
+#pragma unroll
+        for (int j = 0; j < 16; j++) my[t + T * j] = acc[j];
+        sync();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int i = t + T * j;
+            if (T * (j + 1) <= keep2) acc[j] = my[i + h2];
+            else if (T * j >= keep2) acc[j] = v2f{0.f, 0.f};
+            else acc[j] = i < keep2 ? my[i + h2] : v2f{0.f, 0.f};
+        }
+        sync();   // ... before the next frame's window goes through the same area
+        if (active && g == d.G - 1) {
+            // what is left (N - hop samples) lies past the owned range: the next segment's head (tail buffer) or the utterance's end
+            v2f* dst = d.has_next ? tout : xout_p + owned2;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = t + T * j;
+                if (T * j < keep2 && i < keep2) dst[i] = acc[j];
+            }
+        }
+    }
+}
+
 // =============================================================================================== fused path, fp64 ("64-bit mode")
 // The same sliding-window kernel in double precision: what makes 64-bit mode (the only mode that agrees with the reference's fp64
 // arithmetic on EVERY input) affordable.  Same segments, same ownership / tail rule, same lane-slot magnitude

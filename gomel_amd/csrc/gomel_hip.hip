@@ -534,7 +534,14 @@ static int fused_shift(const gomel_config& c) {
     const int sh = c.window / row;
     return (sh == 1 || sh == 2 || sh == 4 || sh == 5 || sh == 8) ? sh : 0;
 }
-static bool fused_applicable(const gomel_config& c) { return fused_shift(c) != 0; }
+// Every other even hop below N: k_gl_fused_any (the same sliding window, shifted through LDS).  gmin = frames a stream must walk so
+// that what it adds past its own samples reaches into the next segment only.
+static int fused_gmin(const gomel_config& c) { return c.window > 0 ? (c.resolut - 1) / c.window : 0; }   // ceil((N - hop) / hop)
+static bool fused_any_ok(const gomel_config& c) {
+    return gomel_supported_n(c.resolut) && c.window > 0 && c.window % 2 == 0 && c.window < c.resolut && fused_gmin(c) <= 31;
+}
+static int fused_kind(const gomel_config& c) { return fused_shift(c) ? 1 : fused_any_ok(c) ? 2 : 0; }   // 1 k_gl_fused, 2 k_gl_fused_any
+static bool fused_applicable(const gomel_config& c) { return fused_kind(c) != 0; }
 
 // The persistent kernel (k_gl_persist) wants 16-byte quads that never straddle a hop (hop and N multiples of 4), at most
 // kPersistMaxNb neighbours on each side, and one of the register FFT cores.
@@ -576,11 +583,9 @@ static int persist_census(gomel_handle* h, int occ) {   // occ 1 / 2: the fp32 k
 // run every frame in parallel: measured crossovers for gmin = 3 (scripts/cross_probe2.py, 60 iterations, one launch per
 // iteration): 1.5 k frames at N 4096, 2.5 k at 2048, 3 k at 1024, 6 k at 512, 12 k at 256; scaled with gmin.
 static int64_t fused_min_frames(const gomel_config& c) {
-    const int sh = fused_shift(c);
-    if (!sh) return INT64_MAX;
+    if (!fused_kind(c)) return INT64_MAX;
     const int64_t base = c.resolut >= 4096 ? 1536 : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288;
-    const int gmin = (16 - sh + sh - 1) / sh;
-    return base * gmin / 3;
+    return base * std::max(1, fused_gmin(c)) / 3;
 }
 
 // Segment plan of the fused kernel.  What matters (scripts/chunk_probe.py): segments of 25-40 frames amortise the 16-row
@@ -590,7 +595,7 @@ static int64_t fused_min_frames(const gomel_config& c) {
 // r * 512 * STREAMS segments in total, and give each utterance its share in proportion to its frames.
 static void plan_segments(gomel_batch* b) {
     const gomel_config& c = b->h->cfg;
-    const int sh = fused_shift(c), keep = 16 - sh, gmin = (keep + sh - 1) / sh;
+    const int gmin = std::max(1, fused_gmin(c));
     const int streams = kFusedThreads / (c.resolut / 32);                      // segments per workgroup (T = N/32 lanes per stream)
     const int64_t per_round = (int64_t)512 * streams;
     int64_t rounds = std::max<int64_t>(1, (b->total_frames + 14 * per_round) / (28 * per_round));
@@ -672,8 +677,16 @@ static hipError_t launch_fused_d(gomel_batch* b, int cur) {
     GOMEL_DISPATCH_N(N, e = launch_fused_d_n<NN>(b, cur, sh));
     return e;
 }
+template <int N> static void launch_fused_any(gomel_batch* b, int cur) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = kFusedThreads / G::T;
+    const int n = (int)b->segs.size();
+    hipLaunchKernelGGL(k_gl_fused_any<N>, dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], b->d_tail[cur],
+                       b->d_x[cur ^ 1], b->d_tail[cur ^ 1], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, b->h->cfg.window, b->h->dt);
+}
 static void launch_fused(gomel_batch* b, int cur) {
     const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
+    if (b->fast == 2) { GOMEL_DISPATCH_N(N, launch_fused_any<NN>(b, cur)); return; }
     GOMEL_DISPATCH_N(N, launch_fused_n<NN>(b, cur, sh));
 }
 
@@ -859,7 +872,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             tm->dom_ms += ms;
         }
         tm->iter_launches = persist ? std::min(I, 1) : I;
-        tm->fast_path = persist ? 2 : b->fast;
+        tm->fast_path = persist ? 2 : b->fast == 2 ? 3 : b->fast;
         tm->frames = b->total_frames;
     }
     return GOMEL_OK;
@@ -1126,8 +1139,9 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             b->err_slot = h->err_free.back(); h->err_free.pop_back();
         }
     }
-    b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && fused_applicable(c) &&
-               (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? 1 : 0;   // (fused_applicable is false for generic lengths)
+    const int kind = b->precise && fused_kind(c) == 2 ? 0 : fused_kind(c);   // (0 for generic lengths; the any-hop kernel has no fp64 build)
+    b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && kind &&
+               (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? kind : 0;
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     int rc = GOMEL_OK;
     const hipStream_t ist = init_stream ? init_stream : h->stream;

@@ -306,7 +306,7 @@ class Batch:
         t = GomelTiming()
         check(_lib.lib().gomel_batch_run_timed(self._b, ctypes.byref(t)), "gomel_batch_run_timed")
         return {"total_ms": t.total_ms, "iter_ms": t.iter_ms, "dom_ms": t.dom_ms, "iter_launches": t.iter_launches,
-                "fast_path": t.fast_path, "frames": t.frames, "dom_kernel": ("k_gl_frames", "k_gl_fused", "k_gl_persist")[t.fast_path]}
+                "fast_path": t.fast_path, "frames": t.frames, "dom_kernel": ("k_gl_frames", "k_gl_fused", "k_gl_persist", "k_gl_fused_any")[t.fast_path]}
 
     def sync(self):
         check(_lib.lib().gomel_batch_sync(self._b), "gomel_batch_sync")

@@ -72,7 +72,8 @@ typedef struct gomel_timing {
     float iter_ms;         /* the Griffin-Lim iteration launches only (sum over iterations)               */
     float dom_ms;          /* the dominant kernel alone, summed over its launches (events around each)    */
     int32_t iter_launches; /* number of dominant-kernel launches                                          */
-    int32_t fast_path;     /* 0 = generic frames + overlap-add kernels, 1 = fused sliding-window kernel, 2 = persistent kernel */
+    int32_t fast_path;     /* 0 = generic frames + overlap-add kernels, 1 = fused sliding-window kernel, 2 = persistent kernel,
+                              3 = fused kernel, any-even-hop form */
     int64_t frames;        /* frames processed                                                            */
 } gomel_timing;
 

@@ -514,3 +514,37 @@ def test_two_ranks_on_one_gpu_with_real_engines(oracle):
     mels = [oracle.random_logmel(f, 80, seed=i) for i, f in enumerate(frames)]
     single = m.engine().from_mel_batch(mels, None, list(range(len(mels))))
     assert [o.tobytes() for o in single] == got[0][1]
+
+
+ANY_HOPS = [(4096, 882, 96), (4096, 1000, 96), (4096, 2050, 96), (4096, 3000, 96), (2048, 276, 80), (2048, 300, 80), (2048, 130, 80), (1024, 300, 80),
+            (1024, 200, 80), (1024, 600, 80), (1024, 34, 40), (512, 100, 40), (512, 510, 40), (256, 50, 40), (256, 18, 40)]
+
+
+@pytest.mark.parametrize("N,hop,K", ANY_HOPS)
+def test_any_hop_fused_kernel_matches_generic_and_oracle(oracle, N, hop, K):
+    """k_gl_fused_any: the sliding-window kernel for even hops that are no multiple of N/16 (the window and the overlap-add
+    accumulator move through LDS by hop/2 pairs per frame).  Against the generic kernels on a ragged batch (same arithmetic per
+    frame, other summation order of the overlap-add: rounding level) and against the fp64 oracle."""
+    import gomel_amd
+    fields = dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=3)
+    gmin = (N - 1) // hop
+    frames = [gmin * 4 + 3, 1, 2, gmin + 1, 150, 64, 65]
+    mels = [oracle.random_logmel(f, K, seed=300 + i) for i, f in enumerate(frames)]
+    seeds = list(range(len(frames)))
+    outs = {}
+    for path in (2, 1):
+        m = mel_obj(fields)
+        e = m.engine()
+        e.set_path(path)
+        b = gomel_amd.Batch(e, [len(mm) for mm in mels])
+        b.upload(mels, None, seeds)
+        tm = b.run_timed()
+        assert tm["fast_path"] == (3 if path == 2 else 0), tm
+        outs[path] = b.download()
+        b.close(); e.close()
+    for a, r in zip(outs[2], outs[1]):
+        assert a.shape == r.shape and rms(a - r) < 2e-6 * max(1.0, rms(r)), rms(a - r)
+    cfg = oracle.MelConfig(**fields)
+    for i in (0, 1, 4):
+        want = oracle.from_mel(cfg, mels[i].copy(), oracle.x0_splitmix(seeds[i], len(outs[2][i])))
+        assert rms(outs[2][i] - want) < RMS_TOL

@@ -1027,12 +1027,18 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 // frame that is two extra LDS passes -- the input window before the forward FFT (its registers then already hold the next
 // frame's window, and the loads of its hop new samples fly during the FFTs, exactly as in k_gl_fused), the overlap-add
 // accumulator after the inverse -- which a mock measured at +8 % of the fused kernel's time, against the 2.3x of the generic
-// kernels (two launches, the frames' windowed outputs through HBM).  Same segments, same ownership / tail rule as k_gl_fused
-// (a segment owns the samples [s0, s0 + G hop); what its frames add beyond goes to its tail buffer, N - hop floats), runtime hop,
-// one instantiation per N.  Needs: hop even, hop < N, and the planner's G >= ceil((N - hop) / hop) for segments with a successor.
-template <int N>
-__global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* __restrict__ x_in, const float* __restrict__ tail_in,
-                                                         float* __restrict__ x_out, float* __restrict__ tail_out,
+// kernels (two launches, the frames' windowed outputs through HBM).  Same segments and ownership as k_gl_fused (a segment owns
+// the samples [s0, s0 + G hop); what its frames add beyond goes to its tail buffer, N - hop floats), but the tails are FOLDED into
+// x by a small kernel behind every launch (k_add_tails<float>, in place: +3 % of the iteration) instead of being read beside x by
+// the next iteration: with a runtime hop the "does this pair reach into the successor's head" test would sit in front of every
+// load of the last ceil((N-hop)/hop) frames of every segment -- a quarter of all frames at hop = N/7.  Runtime hop, one
+// builds per N.  Needs: hop even, hop < N, and the planner's G >= ceil((N - hop) / hop) for segments with a successor.
+// NR = how many of the 16 rows may receive new samples when the window moves on (rows 16-NR .. 15; the host picks the smallest
+// of 4 / 8 / 16 that covers hop/2 pairs): those rows load from memory in straight-line code and select by lane; the others only
+// read LDS.  Deciding that per row at run time put every load behind a branch, and the waits the compiler places at such joins
+// (vmcnt(0) before each LDS read) serialised the frame: 0.87 ms per launch at N 4096 against 0.60 for k_gl_fused.
+template <int N, int NR>
+__global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* __restrict__ x_in, float* __restrict__ x_out, float* __restrict__ tail_out,
                                                          const SegDesc* __restrict__ segs, int n_segs, int g_max,
                                                          const float* __restrict__ mag, const float* __restrict__ nyq, int hop, DevTables tb) {
     typedef Geo<N> G;
@@ -1066,16 +1072,12 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
     constexpr bool WU = (T >= 64);
     auto uo = [](long long v) { if constexpr (WU) return uniform_i64(v); else return v; };
     const int h2 = hop / 2, keep2 = P - h2;                                   // pairs a frame moves on by / shares with its successor
-    const int seg_prev = d.has_prev ? seg - 1 : seg;
     const v2f* xin_p = reinterpret_cast<const v2f*>(x_in) + uo(d.s0 / 2);     // pair i of frame g: xin_p[g h2 + i]
     v2f* xout_p = reinterpret_cast<v2f*>(x_out) + uo(d.s0 / 2);
-    const v2f* tprev = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg_prev * keep2);
-    const v2f* town = reinterpret_cast<const v2f*>(tail_in) + uo((int64_t)seg * keep2);
     v2f* tout = reinterpret_cast<v2f*>(tail_out) + uo((int64_t)seg * keep2);
     const float* mag_p = mag + uo(d.frame0 * G::C);
     const float* nyq_p = nyq + uo(d.frame0);
-    const float f_prev = d.has_prev ? 1.f : 0.f, f_next = d.has_next ? 1.f : 0.f;
-    const int owned2 = d.G * h2;   // pairs >= this (segment-relative) belong to the next segment's head: x + tail[seg] there
+    const int owned2 = d.G * h2;   // pairs >= this (segment-relative) belong to the next segment
     if constexpr (STREAMS > 1) {
         __shared__ int g_sh[STREAMS];
         if (t == 0) g_sh[stream] = live ? d.G : 0;
@@ -1092,12 +1094,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
     v2f wn[8];
     make_wn<G>(wn, t, tb.wn[t]);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {   // the first frame's window: x, the predecessor's tail over its first N - hop samples, the own tail past the owned range
-        const int i = t + T * j;
-        v2f a = xin_p[i];
-        a += tprev[i < keep2 ? i : 0] * (i < keep2 ? f_prev : 0.f);
-        a += town[i >= owned2 ? i - owned2 : 0] * (i >= owned2 ? f_next : 0.f);   // i - owned2 < keep2 because G >= 1
-        xin[j] = a;
+    for (int j = 0; j < 16; j++) {   // the first frame's window (x is complete: the tails of the previous iteration have been folded in)
+        xin[j] = xin_p[t + T * j];
         acc[j] = v2f{0.f, 0.f};
     }
     float nyq_all = 0.f;
@@ -1106,6 +1104,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
         nyq_all = nyq_p[l < d.G ? l : 0];
         asm volatile("v_mov_b32 %0, %0" : "+v"(nyq_all));
     }
+    // the first window must have ARRIVED before the loop: were its loads still in flight at the loop header, the compiler would
+    // count them down in front of the first LDS writes of every frame (vmcnt is in issue order) -- and in steady state that
+    // countdown waits for the previous frame's stores instead
+#pragma unroll
+    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(xin[j]));
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
@@ -1123,23 +1126,18 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
         // loads are in flight during the FFTs; nothing reads xin again before the next frame)
         const bool more = g + 1 < d.G;
         const int base2 = (g + 1) * h2;                                   // segment-relative pair index of the next frame's pair 0
-        const bool any_next = more && d.has_next && base2 + P > owned2;  // ... whose end reaches into the next segment's head
 #pragma unroll
         for (int j = 0; j < 16; j++) my[t + T * j] = xin[j];
         sync();
+        const unsigned nb2 = (unsigned)(more ? base2 : 0);               // (clamped address when there is no next frame)
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int i = t + T * j;
-            if (T * (j + 1) <= keep2) xin[j] = my[i + h2];                 // whole row stays (wave-uniform test)
-            else if (T * j >= keep2) xin[j] = xin_p[more ? base2 + i : i]; // whole row new (clamped address when there is no next frame)
-            else xin[j] = i < keep2 ? my[i + h2] : xin_p[more ? base2 + i : i];
-        }
-        if (any_next) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int i = t + T * j, pp = base2 + i;
-                if (T * (j + 1) > keep2) xin[j] += town[(i >= keep2 && pp >= owned2) ? pp - owned2 : 0] * ((i >= keep2 && pp >= owned2) ? 1.f : 0.f);
-            }
+            const v2f a = my[i < keep2 ? i + h2 : 0];                      // the pair that moves down to this slot, if one does
+            if (j >= 16 - NR) {                                            // (compile-time) rows that may take new samples: by lane
+                const v2f gl = xin_p[nb2 + (unsigned)i];
+                xin[j] = i < keep2 ? a : gl;
+            } else xin[j] = a;
         }
         sync();   // the exchange area goes to the FFT now
         fft_forward<G>(v, my, t, tw, sync);
@@ -1149,15 +1147,22 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
             spectral_apply<G>(v, t, mr, wn);
         }
         fft_inverse<G>(v, my, t, tw, sync);
+        // The next frame's new samples have had two FFTs to arrive: take delivery HERE, before this frame's stores are issued.
+        // vmcnt counts loads and stores in issue order and the stores below sit behind wave-uniform branches (their number is not
+        // known at compile time), so a wait for these loads placed after them -- at the top of the next frame -- would be a
+        // vmcnt(0): a full store round trip per frame (measured: the whole difference to k_gl_fused, 30 % at N 4096).
+#pragma unroll
+        for (int j = 0; j < 16; j++) asm volatile("" : "+v"(xin[j]));
+        __builtin_amdgcn_sched_barrier(0);
         // overlap-add in registers; the first hop/2 pairs are finished by this frame and leave; the rest moves down by hop/2 pairs
 #pragma unroll
         for (int j = 0; j < 16; j++) acc[j] += v[j] * wl[T * j];
         if (active) {
             v2f* xo = xout_p + g * h2;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
+            for (int j = 0; j < NR; j++) {                                 // hop/2 <= NR T - T + ... pairs: rows 0 .. NR-1 hold every finished pair
                 const int i = t + T * j;
-                if (T * j < h2 && i < h2) xo[i] = acc[j];
+                if (i < h2) xo[i] = acc[j];
             }
         }
         sync();   // the inverse FFT's last reads of the exchange area are done
@@ -1167,9 +1172,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int i = t + T * j;
-            if (T * (j + 1) <= keep2) acc[j] = my[i + h2];
-            else if (T * j >= keep2) acc[j] = v2f{0.f, 0.f};
-            else acc[j] = i < keep2 ? my[i + h2] : v2f{0.f, 0.f};
+            const v2f a = my[i < keep2 ? i + h2 : 0];
+            acc[j] = i < keep2 ? a : v2f{0.f, 0.f};
         }
         sync();   // ... before the next frame's window goes through the same area
         if (active && g == d.G - 1) {
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int i = t + T * j;
-                if (T * j < keep2 && i < keep2) dst[i] = acc[j];
+                if (i < keep2) dst[i] = acc[j];
             }
         }
     }

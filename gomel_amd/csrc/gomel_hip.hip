@@ -540,7 +540,11 @@ static int fused_gmin(const gomel_config& c) { return c.window > 0 ? (c.resolut 
 static bool fused_any_ok(const gomel_config& c) {
     return gomel_supported_n(c.resolut) && c.window > 0 && c.window % 2 == 0 && c.window < c.resolut && fused_gmin(c) <= 31;
 }
-static int fused_kind(const gomel_config& c) { return fused_shift(c) ? 1 : fused_any_ok(c) ? 2 : 0; }   // 1 k_gl_fused, 2 k_gl_fused_any
+static int fused_kind(const gomel_config& c) {   // 1 k_gl_fused, 2 k_gl_fused_any
+    static const bool prefer_any = getenv("GOMEL_FORCE_ANY") != nullptr;   // A/B knob: the any-hop kernel at an aligned hop
+    if (prefer_any && fused_any_ok(c)) return 2;
+    return fused_shift(c) ? 1 : fused_any_ok(c) ? 2 : 0;
+}
 static bool fused_applicable(const gomel_config& c) { return fused_kind(c) != 0; }
 
 // The persistent kernel (k_gl_persist) wants 16-byte quads that never straddle a hop (hop and N multiples of 4), at most
@@ -681,8 +685,15 @@ template <int N> static void launch_fused_any(gomel_batch* b, int cur) {
     typedef Geo<N> G;
     constexpr int STREAMS = kFusedThreads / G::T;
     const int n = (int)b->segs.size();
-    hipLaunchKernelGGL(k_gl_fused_any<N>, dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], b->d_tail[cur],
-                       b->d_x[cur ^ 1], b->d_tail[cur ^ 1], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, b->h->cfg.window, b->h->dt);
+    // rows of the window that take new samples: the last ceil(hop/2 / T) of the 16 (16 T pairs in all)
+    const int h2 = b->h->cfg.window / 2, rows_new = (h2 + G::T - 1) / G::T;
+#define GOMEL_ANY_LAUNCH(NR)                                                                                                                        \
+    hipLaunchKernelGGL((k_gl_fused_any<N, NR>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], \
+                       b->d_x[cur ^ 1], b->d_tail[0], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, b->h->cfg.window, b->h->dt)
+    if (rows_new <= 4) GOMEL_ANY_LAUNCH(4); else if (rows_new <= 8) GOMEL_ANY_LAUNCH(8); else GOMEL_ANY_LAUNCH(16);
+#undef GOMEL_ANY_LAUNCH
+    // fold what the segments added past their own samples into x, in place: the next iteration (and k_finalize) read x alone
+    hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)n), dim3(256), 0, b->h->stream, b->d_segs, b->d_tail[0], b->d_x[cur ^ 1], N - b->h->cfg.window, b->h->cfg.window);
 }
 static void launch_fused(gomel_batch* b, int cur) {
     const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
@@ -849,10 +860,10 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             // k_ola_out has written the waveforms
         } else if (b->io32) {
             hipLaunchKernelGGL(k_finalize<float>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out32, b->total_len);
-            if (b->fast) hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out32, N - c.window, c.window);
+            if (b->fast == 1) hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out32, N - c.window, c.window);
         } else {
             hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
-            if (b->fast) hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
+            if (b->fast == 1) hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
         }
         }
     }

@@ -121,3 +121,23 @@ def test_persistent_kernel_builds_fit_their_occupancy(isa):
     assert len(stores) >= 16 and all(" sc1" in l for l in stores)        # eight sentinel quads + eight fresh quads per iteration
     assert len(loads) >= 24 and all(" sc1" in l for l in loads)          # the gather: up to 32 quads, every one of them write-through-coherent
     assert not any("buffer_inv" in l or "buffer_wbl2" in l for l in body)
+
+
+def test_any_hop_fused_kernel_has_no_flat_loads_no_spills_no_waits_at_the_loop_top(isa):
+    """k_gl_fused_any lost 30 % to three code-generation accidents, each visible in the ISA: a select between an LDS
+    and a global ADDRESS became a flat load (after which every LDS read waits for every global load), loads behind per-row branches
+    got vmcnt(0) at every join, and the prologue's loads were counted down in front of every frame's LDS writes.  Keep them out."""
+    text = "\n".join(isa)
+    found = re.findall(r"\.name:\s+(_Z14k_gl_fused_anyILi(\d+)ELi(\d+)E\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(found) == 15, [f[0] for f in found]                     # five frame lengths x three new-row counts
+    for name, n, nr, vgpr, spill in found:
+        # (the 16-row build -- hops above 7N/16, two covering frames -- holds 16 loaded rows beside 16 LDS rows: a few spills at N 4096)
+        assert int(nr) in (4, 8, 16) and int(vgpr) <= 256 and int(spill) <= (0 if int(nr) < 16 else 48), (n, nr, vgpr, spill)
+    for inst in ("_Z14k_gl_fused_anyILi4096ELi4EE", "_Z14k_gl_fused_anyILi2048ELi4EE", "_Z14k_gl_fused_anyILi1024ELi8EE"):
+        body = isa[next(i for i, l in enumerate(isa) if l.startswith(inst) and ":" in l):]
+        body = body[:next(i for i, l in enumerate(body) if "s_endpgm" in l)]
+        assert not any("flat_load" in l or "flat_store" in l or "scratch_" in l for l in body), inst
+        loop = body[max(i for i, l in enumerate(body) if "Loop Header" in l):]             # the frame loop (the table staging loops come first)
+        first_lds_write = next(i for i, l in enumerate(loop) if "ds_write_b64" in l)
+        assert not any("s_waitcnt vmcnt" in l for l in loop[:first_lds_write]), inst      # nothing to wait for before the window goes to LDS
+        assert sum("s_waitcnt vmcnt(0)" in l for l in loop) <= 2, inst                      # (one where the next window's loads are taken in)

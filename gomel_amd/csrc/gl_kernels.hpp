@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #endif
 }
 
-// =============================================================================================== fused path, any even hop
+// =============================================================================================== fused path, any hop
 // k_gl_fused covers hop = SH * N/16 because there moving to the next frame is a shift by whole register rows.  For every other
 // (even) hop the same sliding-window scheme works with ONE more idea: rows are just the linear pair index i = t + T j cut into 16
 // pieces, so a shift by hop/2 pairs is "write the 16 rows to the stream's LDS area, read them back hop/2 slots further".  Per
@@ -1037,13 +1037,17 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 // of 4 / 8 / 16 that covers hop/2 pairs): those rows load from memory in straight-line code and select by lane; the others only
 // read LDS.  Deciding that per row at run time put every load behind a branch, and the waits the compiler places at such joins
 // (vmcnt(0) before each LDS read) serialised the frame: 0.87 ms per launch at N 4096 against 0.60 for k_gl_fused.
-template <int N, int NR>
+// ODD = the hop is odd: a frame then starts in the middle of a pair of its predecessor, so the shift runs on floats instead of
+// pairs -- LDS reads of 8 bytes at 4-byte alignment (ds_read2_b32), two selects per pair, global accesses dword-aligned, and the
+// one float that ends a frame's finished (or a segment's left-over) samples stored on its own.
+template <int N, int NR, bool ODD>
 __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* __restrict__ x_in, float* __restrict__ x_out, float* __restrict__ tail_out,
                                                          const SegDesc* __restrict__ segs, int n_segs, int g_max,
                                                          const float* __restrict__ mag, const float* __restrict__ nyq, int hop, DevTables tb) {
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = kFusedThreads / T, P = N / 2;
-    static_assert(G::LDS_SLOTS >= P, "the stream's exchange area must take one window of pairs");
+    static_assert(G::LDS_SLOTS > P, "the stream's exchange area must take one window of pairs (and the float behind it)");
+    typedef v2f v2f_a4 __attribute__((aligned(4)));
     __shared__ v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
     v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
     v2f* tw2_l = tw1_l + G::TW1_N;
@@ -1075,6 +1079,12 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
     const v2f* xin_p = reinterpret_cast<const v2f*>(x_in) + uo(d.s0 / 2);     // pair i of frame g: xin_p[g h2 + i]
     v2f* xout_p = reinterpret_cast<v2f*>(x_out) + uo(d.s0 / 2);
     v2f* tout = reinterpret_cast<v2f*>(tail_out) + uo((int64_t)seg * keep2);
+    // the same in floats (ODD): hop floats per frame, keepf = N - hop shared with the successor / left over at a segment's end
+    const int keepf = N - hop;
+    const float* xin_f = x_in + uo(d.s0);
+    float* xout_f = x_out + uo(d.s0);
+    float* tout_f = tail_out + uo((int64_t)seg * keepf);
+    const float* myf = reinterpret_cast<const float*>(lds + stream * G::LDS_SLOTS);
     const float* mag_p = mag + uo(d.frame0 * G::C);
     const float* nyq_p = nyq + uo(d.frame0);
     const int owned2 = d.G * h2;   // pairs >= this (segment-relative) belong to the next segment
@@ -1095,7 +1105,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
     make_wn<G>(wn, t, tb.wn[t]);
 #pragma unroll
     for (int j = 0; j < 16; j++) {   // the first frame's window (x is complete: the tails of the previous iteration have been folded in)
-        xin[j] = xin_p[t + T * j];
+        if constexpr (ODD) xin[j] = *reinterpret_cast<const v2f_a4*>(xin_f + 2 * (t + T * j));
+        else xin[j] = xin_p[t + T * j];
         acc[j] = v2f{0.f, 0.f};
     }
     float nyq_all = 0.f;
@@ -1130,14 +1141,24 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
         for (int j = 0; j < 16; j++) my[t + T * j] = xin[j];
         sync();
         const unsigned nb2 = (unsigned)(more ? base2 : 0);               // (clamped address when there is no next frame)
+        const unsigned nbf = (unsigned)(more ? (g + 1) * hop : 0);       // the same in floats
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int i = t + T * j;
-            const v2f a = my[i < keep2 ? i + h2 : 0];                      // the pair that moves down to this slot, if one does
-            if (j >= 16 - NR) {                                            // (compile-time) rows that may take new samples: by lane
-                const v2f gl = xin_p[nb2 + (unsigned)i];
-                xin[j] = i < keep2 ? a : gl;
-            } else xin[j] = a;
+            if constexpr (ODD) {
+                const int f0 = 2 * i + hop;                               // the floats that move down to this slot: f0, f0 + 1, if inside the window
+                const v2f a = *reinterpret_cast<const v2f_a4*>(myf + (f0 < N ? f0 : 0));
+                if (j >= 16 - NR) {
+                    const v2f gl = *reinterpret_cast<const v2f_a4*>(xin_f + nbf + 2u * (unsigned)i);
+                    xin[j] = v2f{f0 < N ? a.x : gl.x, f0 + 1 < N ? a.y : gl.y};
+                } else xin[j] = a;
+            } else {
+                const v2f a = my[i < keep2 ? i + h2 : 0];                  // the pair that moves down to this slot, if one does
+                if (j >= 16 - NR) {                                        // (compile-time) rows that may take new samples: by lane
+                    const v2f gl = xin_p[nb2 + (unsigned)i];
+                    xin[j] = i < keep2 ? a : gl;
+                } else xin[j] = a;
+            }
         }
         sync();   // the exchange area goes to the FFT now
         fft_forward<G>(v, my, t, tw, sync);
@@ -1159,10 +1180,16 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
         for (int j = 0; j < 16; j++) acc[j] += v[j] * wl[T * j];
         if (active) {
             v2f* xo = xout_p + g * h2;
+            float* xof = xout_f + g * hop;
 #pragma unroll
-            for (int j = 0; j < NR; j++) {                                 // hop/2 <= NR T - T + ... pairs: rows 0 .. NR-1 hold every finished pair
+            for (int j = 0; j < NR; j++) {                                 // rows 0 .. NR-1 hold every finished sample (host: NR covers them)
                 const int i = t + T * j;
-                if (i < h2) xo[i] = acc[j];
+                if constexpr (ODD) {
+                    if (2 * i + 1 < hop) *reinterpret_cast<v2f_a4*>(xof + 2 * i) = acc[j];
+                    else if (2 * i < hop) xof[2 * i] = acc[j].x;            // the odd hop's last sample
+                } else {
+                    if (i < h2) xo[i] = acc[j];
+                }
             }
         }
         sync();   // the inverse FFT's last reads of the exchange area are done
@@ -1172,17 +1199,29 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int i = t + T * j;
-            const v2f a = my[i < keep2 ? i + h2 : 0];
-            acc[j] = i < keep2 ? a : v2f{0.f, 0.f};
+            if constexpr (ODD) {
+                const int f0 = 2 * i + hop;
+                const v2f a = *reinterpret_cast<const v2f_a4*>(myf + (f0 < N ? f0 : 0));
+                acc[j] = v2f{f0 < N ? a.x : 0.f, f0 + 1 < N ? a.y : 0.f};
+            } else {
+                const v2f a = my[i < keep2 ? i + h2 : 0];
+                acc[j] = i < keep2 ? a : v2f{0.f, 0.f};
+            }
         }
         sync();   // ... before the next frame's window goes through the same area
         if (active && g == d.G - 1) {
             // what is left (N - hop samples) lies past the owned range: the next segment's head (tail buffer) or the utterance's end
             v2f* dst = d.has_next ? tout : xout_p + owned2;
+            float* dstf = d.has_next ? tout_f : xout_f + d.G * hop;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int i = t + T * j;
-                if (i < keep2) dst[i] = acc[j];
+                if constexpr (ODD) {
+                    if (2 * i + 1 < keepf) *reinterpret_cast<v2f_a4*>(dstf + 2 * i) = acc[j];
+                    else if (2 * i < keepf) dstf[2 * i] = acc[j].x;
+                } else {
+                    if (i < keep2) dst[i] = acc[j];
+                }
             }
         }
     }

@@ -538,7 +538,7 @@ static int fused_shift(const gomel_config& c) {
 // that what it adds past its own samples reaches into the next segment only.
 static int fused_gmin(const gomel_config& c) { return c.window > 0 ? (c.resolut - 1) / c.window : 0; }   // ceil((N - hop) / hop)
 static bool fused_any_ok(const gomel_config& c) {
-    return gomel_supported_n(c.resolut) && c.window > 0 && c.window % 2 == 0 && c.window < c.resolut && fused_gmin(c) <= 31;
+    return gomel_supported_n(c.resolut) && c.window > 0 && c.window < c.resolut && fused_gmin(c) <= 31;
 }
 static int fused_kind(const gomel_config& c) {   // 1 k_gl_fused, 2 k_gl_fused_any
     static const bool prefer_any = getenv("GOMEL_FORCE_ANY") != nullptr;   // A/B knob: the any-hop kernel at an aligned hop
@@ -685,12 +685,15 @@ template <int N> static void launch_fused_any(gomel_batch* b, int cur) {
     typedef Geo<N> G;
     constexpr int STREAMS = kFusedThreads / G::T;
     const int n = (int)b->segs.size();
-    // rows of the window that take new samples: the last ceil(hop/2 / T) of the 16 (16 T pairs in all)
-    const int h2 = b->h->cfg.window / 2, rows_new = (h2 + G::T - 1) / G::T;
-#define GOMEL_ANY_LAUNCH(NR)                                                                                                                        \
-    hipLaunchKernelGGL((k_gl_fused_any<N, NR>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], \
-                       b->d_x[cur ^ 1], b->d_tail[0], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, b->h->cfg.window, b->h->dt)
-    if (rows_new <= 4) GOMEL_ANY_LAUNCH(4); else if (rows_new <= 8) GOMEL_ANY_LAUNCH(8); else GOMEL_ANY_LAUNCH(16);
+    // rows of the window that take new samples (the last ones of the 16: pairs from floor((N - hop) / 2) on) and rows that hold
+    // finished samples (the first ones: pairs up to (hop - 1) / 2): NR must cover both
+    const int hop = b->h->cfg.window;
+    const int rows_new = std::max(16 - ((N - hop) / 2) / G::T, ((hop - 1) / 2) / G::T + 1);
+#define GOMEL_ANY_LAUNCH(NR, ODD)                                                                                                                       \
+    hipLaunchKernelGGL((k_gl_fused_any<N, NR, ODD>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], \
+                       b->d_x[cur ^ 1], b->d_tail[0], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, hop, b->h->dt)
+    if (hop & 1) { if (rows_new <= 4) GOMEL_ANY_LAUNCH(4, true); else if (rows_new <= 8) GOMEL_ANY_LAUNCH(8, true); else GOMEL_ANY_LAUNCH(16, true); }
+    else { if (rows_new <= 4) GOMEL_ANY_LAUNCH(4, false); else if (rows_new <= 8) GOMEL_ANY_LAUNCH(8, false); else GOMEL_ANY_LAUNCH(16, false); }
 #undef GOMEL_ANY_LAUNCH
     // fold what the segments added past their own samples into x, in place: the next iteration (and k_finalize) read x alone
     hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)n), dim3(256), 0, b->h->stream, b->d_segs, b->d_tail[0], b->d_x[cur ^ 1], N - b->h->cfg.window, b->h->cfg.window);

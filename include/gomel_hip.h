@@ -185,7 +185,7 @@ int gomel_batch_destroy(gomel_batch* b);
  * persistent kernel -- every iteration in one launch -- when all frames of the batch fit the chip at once, i.e. one utterance
  * or a few short ones, the hop is a multiple of 4 and at least Resolut/16; generic kernels otherwise);
  * 1 = force the generic kernels; 2 = require a fused kernel (k_gl_fused when the hop is SH*Resolut/16, SH in 1,2,4,5,8; its any-hop
- * form for every other even hop below Resolut; error for odd hops and hops >= Resolut);
+ * form for every other hop from Resolut/32 up to Resolut - 1; error for smaller hops and hops >= Resolut);
  * 3 = require the persistent kernel (gomel_batch_create fails with GOMEL_ERR_BAD_CONFIG for a batch that does not fit it).
  * The persistent kernel's workgroups wait for each other inside the launch: should another context keep them from all being
  * resident, the launch gives up after 20 ms, the batch is recomputed with the generic kernels (same results, bit for bit) and

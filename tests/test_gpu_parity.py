@@ -169,16 +169,16 @@ def test_fused_segments_are_invisible(oracle, monkeypatch):
 
 @pytest.mark.parametrize("hop", [256, 512, 1024, 2048, 1280, 768, 100, 275, 441, 1, 4095])
 def test_hops_fused_and_generic(oracle, hop):
-    """hop = SH*N/16 with SH in {1,2,4,5,8} takes the fused kernel, every other even hop its any-hop form (768 = 3 rows), the rest
-    -- the odd hops 275 = 12.5 ms at 22.05 kHz and 441 = 10 ms at 44.1 kHz, 1, N-1, and hop 100 whose segments would need 40
-    frames of lead -- the generic kernels."""
+    """hop = SH*N/16 with SH in {1,2,4,5,8} takes the fused kernel, every other hop below N its any-hop form (768 = 3 rows; the odd
+    hops 275 = 12.5 ms at 22.05 kHz and 441 = 10 ms at 44.1 kHz; N-1), the rest -- hop 1 and hop 100, whose segments would need
+    more than 31 frames of lead -- the generic kernels."""
     kw = dict(NumMels=192, MelFmax=16000.0, Window=hop, Resolut=4096, GriffinLimIterations=3)
     import gomel_amd
     m = gomel_amd.NewMel()
     for k, v in kw.items():
         setattr(m, k, v)
     cfg = oracle.MelConfig(**kw)
-    if hop % 2 == 0 and hop < 4096 and 4095 // hop <= 31:
+    if hop < 4096 and 4095 // hop <= 31:
         m.engine().set_path(2)                  # must be accepted: a fused kernel takes these hops (and runs the 21 frames below)
     else:
         with pytest.raises(gomel_amd.GomelError):

@@ -517,13 +517,16 @@ def test_two_ranks_on_one_gpu_with_real_engines(oracle):
 
 
 ANY_HOPS = [(4096, 882, 96), (4096, 1000, 96), (4096, 2050, 96), (4096, 3000, 96), (2048, 276, 80), (2048, 300, 80), (2048, 130, 80), (1024, 300, 80),
-            (1024, 200, 80), (1024, 600, 80), (1024, 34, 40), (512, 100, 40), (512, 510, 40), (256, 50, 40), (256, 18, 40)]
+            (1024, 200, 80), (1024, 600, 80), (1024, 34, 40), (512, 100, 40), (512, 510, 40), (256, 50, 40), (256, 18, 40),
+            # odd hops: a frame starts in the middle of a pair
+            (4096, 441, 96), (4096, 4095, 96), (4096, 2049, 96), (2048, 275, 80), (2048, 1025, 80), (1024, 275, 80), (1024, 33, 40), (512, 161, 40),
+            (256, 51, 40), (256, 255, 40), (256, 9, 40)]
 
 
 @pytest.mark.parametrize("N,hop,K", ANY_HOPS)
 def test_any_hop_fused_kernel_matches_generic_and_oracle(oracle, N, hop, K):
-    """k_gl_fused_any: the sliding-window kernel for even hops that are no multiple of N/16 (the window and the overlap-add
-    accumulator move through LDS by hop/2 pairs per frame).  Against the generic kernels on a ragged batch (same arithmetic per
+    """k_gl_fused_any: the sliding-window kernel for hops that are no multiple of N/16 (the window and the overlap-add
+    accumulator move through LDS by hop samples per frame; odd hops shift by floats instead of pairs).  Against the generic kernels on a ragged batch (same arithmetic per
     frame, other summation order of the overlap-add: rounding level) and against the fp64 oracle."""
     import gomel_amd
     fields = dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=3)

@@ -29,6 +29,14 @@ int main(void) {
         if (gomel_to_mel_batch(NULL, 1, mel, np, out, NULL, NULL) != GOMEL_ERR_NULL) return 15;
         if (gomel_host_free(NULL) != GOMEL_OK || gomel_host_register(NULL, 16) != GOMEL_ERR_NULL) return 16;
     }
+    {   /* the pipeline's chunk planner is host logic: 64 utterances of 400 frames at the ToWavPng geometry -> half + full + half */
+        size_t np[64], bounds[66], nch = 0, u;
+        for (u = 0; u < 64; u++) np[u] = (size_t)400 * 192;
+        if (gomel_plan_chunks(&c, 64, np, bounds, 66, &nch) != GOMEL_OK) return 18;
+        if (nch < 2 || bounds[0] != 0 || bounds[nch] != 64) return 19;
+        for (u = 0; u < nch; u++) if (bounds[u + 1] <= bounds[u]) return 20;
+        if (gomel_plan_chunks(&c, 64, np, bounds, 1, &nch) != GOMEL_ERR_BUFFER_TOO_SMALL) return 21;
+    }
     gomel_handle* h = NULL;
     int rc = gomel_create(&c, &h);
     if (gomel_device_count() == 0) {

@@ -212,20 +212,38 @@ struct UttDesc {  // one utterance of a batch
     uint64_t seed;
 };
 
+// Four samples per lane: utterances start 16-byte aligned and are padded to multiples of four samples (batch_create), so the padding
+// takes the (never read) extra values and every access is a full 16 / 32 bytes.
 template <class OutT, class InT>
 __global__ __launch_bounds__(256) void k_init_x(const UttDesc* __restrict__ utts, int n_utt, const InT* __restrict__ x0, OutT* __restrict__ x) {
+    typedef OutT out4 __attribute__((ext_vector_type(4)));
+    typedef InT in4 __attribute__((ext_vector_type(4)));
     for (int iu = blockIdx.y; iu < n_utt; iu += gridDim.y) {   // grid.y is capped at 65535: batches of more utterances stride
         const UttDesc u = utts[iu];
-        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < u.len; n += (int64_t)gridDim.x * blockDim.x) {
-            double v = u.has_x0 ? (double)x0[u.xoff + n] : splitmix_u01(u.seed, (uint64_t)n);
-            x[u.xoff + n] = (OutT)v;
+        const int64_t quads = (u.len + 3) >> 2;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t n = q << 2;
+            out4 o;
+            if (u.has_x0) {
+                const in4 a = *reinterpret_cast<const in4*>(x0 + u.xoff + n);
+                o = out4{(OutT)a.x, (OutT)a.y, (OutT)a.z, (OutT)a.w};
+            } else {
+                o = out4{(OutT)splitmix_u01(u.seed, (uint64_t)n), (OutT)splitmix_u01(u.seed, (uint64_t)n + 1), (OutT)splitmix_u01(u.seed, (uint64_t)n + 2),
+                         (OutT)splitmix_u01(u.seed, (uint64_t)n + 3)};
+            }
+            *reinterpret_cast<out4*>(x + u.xoff + n) = o;
         }
     }
 }
 
 template <class OutT>
-__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, OutT* __restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (OutT)x[i];
+__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, OutT* __restrict__ out, int64_t n) {   // n: a multiple of 4
+    typedef OutT out4 __attribute__((ext_vector_type(4)));
+    const int64_t quads = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+        const v4f a = reinterpret_cast<const v4f*>(x)[q];
+        reinterpret_cast<out4*>(out)[q] = out4{(OutT)a.x, (OutT)a.y, (OutT)a.z, (OutT)a.w};
+    }
 }
 
 // =============================================================================================== generic path: frames kernel

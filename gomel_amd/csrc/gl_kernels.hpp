@@ -1075,7 +1075,17 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
     __syncthreads();
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
-    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr};   // twiddles from LDS: the registers k_gl_fused keeps them in go to the 16-row accumulator here
+    // pass-2 twiddles in registers where the build has room for them (the 4-row builds at even hops: -3 % as in k_gl_fused); the
+    // other builds need the registers for the rows they load, and read every twiddle from LDS
+    constexpr bool W2R = NR == 4 && !ODD && N <= 2048;   // (N 4096: five spilled registers)
+    v2f w2r[16];
+    if constexpr (W2R) {
+#pragma unroll
+        for (int u = 0; u < G::NB2; u++)
+#pragma unroll
+            for (int q = 0; q < G::R2; q++) w2r[u * G::R2 + q] = tb.tw2[q * 8 + (t + G::T * u) / G::R1];
+    }
+    const Twiddles<v2f> tw{tw1_l, tw2_l, nullptr, nullptr, 0, W2R ? w2r : nullptr};
     auto sync = [] {
         if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();

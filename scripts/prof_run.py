@@ -3,6 +3,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+from gomel_amd import _lib
+if os.environ.get("GOMEL_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["GOMEL_LIB"])      # A/B another build
 import gomel_amd
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 400

@@ -595,14 +595,17 @@ static int64_t fused_min_frames(const gomel_config& c) {
 // Segment plan of the fused kernel.  What matters (scripts/chunk_probe.py): segments of 25-40 frames amortise the 16-row
 // prologue and the workgroup's table fill, and the NUMBER of segments should fill whole rounds of the chip: a workgroup takes
 // STREAMS segments and 2 workgroups fit a CU, so one round is 512 workgroups; 533 workgroups cost two rounds (1.75 M frames/s
-// where 512 reach 1.95 M on the same 12 800 frames).  So: pick the number of rounds r for ~28 frames per segment, aim at
+// where 512 reach 1.95 M on the same 12 800 frames).  So: pick the number of rounds r for ~50 frames per segment, aim at
 // r * 512 * STREAMS segments in total, and give each utterance its share in proportion to its frames.
 static void plan_segments(gomel_batch* b) {
     const gomel_config& c = b->h->cfg;
     const int gmin = std::max(1, fused_gmin(c));
     const int streams = kFusedThreads / (c.resolut / 32);                      // segments per workgroup (T = N/32 lanes per stream)
     const int64_t per_round = (int64_t)512 * streams;
-    int64_t rounds = std::max<int64_t>(1, (b->total_frames + 14 * per_round) / (28 * per_round));
+    // ~50 frames per segment where the batch gives two rounds or more (fewer 16-row prologues and table fills: 2 rounds of 50 beat
+    // 4 of 25 by 1 % at config 3, scripts/seg_probe.sh), never above 60 (the kernel's limit is kMaxSegFrames = 64)
+    int64_t rounds = std::max<int64_t>(1, (b->total_frames + 25 * per_round) / (50 * per_round));
+    while (b->total_frames > rounds * per_round * 60) rounds++;
     double target = (double)(rounds * per_round);                              // segments wanted in total
     int forced = 0;
     if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) forced = std::min(std::max(v, gmin), kMaxSegFrames); }  // tuning knob
@@ -1357,7 +1360,9 @@ static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, co
         const int64_t round0 = fused_applicable(cfg) ? (int64_t)512 * (kFusedThreads / (cfg.resolut / 32)) : 0;
         auto fill = [&](int64_t F) {   // fraction of the launch's stream-time that does work (plan_segments' rounds rule)
             if (round0 == 0 || F <= 0) return 1.0;
-            const int64_t slots = std::max<int64_t>(1, (F + 14 * round0) / (28 * round0)) * round0;
+            int64_t rnd = std::max<int64_t>(1, (F + 25 * round0) / (50 * round0));
+            while (F > rnd * round0 * 60) rnd++;
+            const int64_t slots = rnd * round0;
             return (double)F / (double)(slots * ((F + slots - 1) / slots));
         };
         size_t u = 0;

@@ -1680,28 +1680,55 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
     int rc = GOMEL_OK;
     PinnedScope pins;                      // big caller buffers: pinned for the call (pageable copies run at a tenth of the rate)
     for (size_t u = 0; u < n_utt; u++) { pins.want(wave[u], n_samples[u] * 8); pins.want(out_pairs[u], F[u] * (size_t)K * 16); }
-    pins.commit(h->stream);
+    pins.commit(h->stream, h->copy_stream);
+    pins.drain_too(h->up_stream);
     if (h->pool.alloc((void**)&d_wave, tot_w * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, tot_f * (size_t)(H + 1) * 8) != hipSuccess ||
         h->pool.alloc((void**)&d_out, tot_f * (size_t)K * 16) != hipSuccess || h->pool.alloc((void**)&d_fx, tot_f * 8) != hipSuccess) {
         g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
     }
-    if (!rc && hipMemsetAsync(d_wave, 0, tot_w * 8, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
-    for (size_t u = 0; u < n_utt && !rc; u++)
-        if (hipMemcpyAsync(d_wave + woff[u], wave[u], n_samples[u] * 8, hipMemcpyDefault, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
-    if (!rc && hipMemcpyAsync(d_fx, fx.data(), tot_f * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
-    if (!rc) {
+    // Chunks of ~32 MB of samples, pipelined over the handle's three streams as in FromMel's batch call: chunk c+1's waveforms go up
+    // while chunk c is transformed and chunk c-1's log-mel comes down (a 256 x 10 s call is H2D-bound: 0.9 GB up, 0.27 GB down,
+    // 1.5 ms of kernels -- 28.7 ms one thing after the other, the upload's 18 ms plus a chunk's worth overlapped).  The device
+    // buffers cover the whole call; only the streams are staged.
+    std::vector<size_t> cb(1, 0);
+    {
+        size_t acc = 0;
+        for (size_t u = 0; u < n_utt; u++) {
+            acc += n_samples[u] * 8;
+            if (acc >= ((size_t)32 << 20) && u + 1 < n_utt) { cb.push_back(u + 1); acc = 0; }
+        }
+        cb.push_back(n_utt);
+    }
+    const size_t n_ch = cb.size() - 1;
+    std::vector<hipEvent_t> ev_up(n_ch, nullptr), ev_done(n_ch, nullptr);
+    for (size_t cidx = 0; cidx < n_ch && !rc; cidx++)
+        if (hipEventCreateWithFlags(&ev_up[cidx], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_done[cidx], hipEventDisableTiming) != hipSuccess) rc = GOMEL_ERR_HIP;
+    // (the pins were committed against the compute stream: the copies of this call run on the other two, drained below before the pins go)
+    if (!rc && hipMemsetAsync(d_wave, 0, tot_w * 8, h->up_stream) != hipSuccess) rc = GOMEL_ERR_HIP;          // pad's zeros (mel/impl.go:429-455)
+    if (!rc && hipMemcpyAsync(d_fx, fx.data(), tot_f * 8, hipMemcpyHostToDevice, h->up_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    for (size_t cidx = 0; cidx < n_ch && !rc; cidx++) {
+        const size_t u0 = cb[cidx], u1 = cb[cidx + 1];
+        const size_t f0 = foff[u0], nf = (u1 < n_utt ? foff[u1] : tot_f) - f0;
+        for (size_t u = u0; u < u1 && !rc; u++)
+            if (hipMemcpyAsync(d_wave + woff[u], wave[u], n_samples[u] * 8, hipMemcpyDefault, h->up_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+        if (!rc && (hipEventRecord(ev_up[cidx], h->up_stream) != hipSuccess || hipStreamWaitEvent(h->stream, ev_up[cidx], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+        if (rc) break;
         if (h->generic)
-            hipLaunchKernelGGL(glany::k_any_frames<true>, dim3((unsigned)tot_f), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, h->stream,
-                               d_wave, d_fx, (const double*)nullptr, (const double*)nullptr, d_smag, (int64_t)tot_f, N, h->dt.windowd, h->dt.any);
+            hipLaunchKernelGGL(glany::k_any_frames<true>, dim3((unsigned)nf), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, h->stream,
+                               d_wave, d_fx + f0, (const double*)nullptr, (const double*)nullptr, d_smag + f0 * (size_t)(H + 1), (int64_t)nf, N, h->dt.windowd, h->dt.any);
         else
         GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
-                              hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((tot_f + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_fx, d_smag, (int64_t)tot_f, hop, h->dt); });
-        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)tot_f), dim3(256), (size_t)(H + 1) * 8, h->stream, d_smag, h->dt.dom, d_out, K, H);
-        for (size_t u = 0; u < n_utt && !rc; u++)
-            if (hipMemcpyAsync(out_pairs[u], d_out + foff[u] * (size_t)K * 2, F[u] * (size_t)K * 16, hipMemcpyDefault, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
-        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;   // also: fx must outlive its copy
-        if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
+                              hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((nf + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_fx + f0, d_smag + f0 * (size_t)(H + 1), (int64_t)nf, hop, h->dt); });
+        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)nf), dim3(256), (size_t)(H + 1) * 8, h->stream, d_smag + f0 * (size_t)(H + 1), h->dt.dom, d_out + f0 * (size_t)K * 2, K, H);
+        if (hipEventRecord(ev_done[cidx], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, ev_done[cidx], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
+        for (size_t u = u0; u < u1 && !rc; u++)
+            if (hipMemcpyAsync(out_pairs[u], d_out + foff[u] * (size_t)K * 2, F[u] * (size_t)K * 16, hipMemcpyDefault, h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
     }
+    if (hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess)
+        rc = rc ? rc : GOMEL_ERR_HIP;   // also: fx must outlive its copy
+    if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
+    for (hipEvent_t e : ev_up) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : ev_done) if (e) hipEventDestroy(e);
     if (d_wave) h->pool.release(d_wave);
     if (d_smag) h->pool.release(d_smag);
     if (d_out) h->pool.release(d_out);

@@ -388,7 +388,7 @@ def main():
         value = total_frames * args.steps / elapsed
         launches = max(1, tm["iter_launches"])
         t_launch = tm["dom_ms"] / launches * 1e-3
-        bytes_launch = tm["frames"] * algorithmic_bytes_per_frame_iter(N, hop)
+        bytes_launch = tm["frames"] * algorithmic_bytes_per_frame_iter(N, hop) * (I if tm["fast_path"] == 2 else 1)   # the persistent kernel: one launch = all I iterations
         achieved = bytes_launch / t_launch / 1e9
         traffic, traffic_source = committed_traffic(wl if wl != "cfg5" else "cfg3", tm["fast_path"])
         per_frame_bytes = I * algorithmic_bytes_per_frame_iter(N, hop) + fields["NumMels"] * 16 + hop * 8

@@ -410,7 +410,8 @@ def main():
                          "launch": "one launch over the whole %d-utterance batch (the configuration as BASELINE names it), HIP events on the library's stream in this process" % min(n_utt, BLOCK),
                          "timed_region_launches": {"what": "the same kernel at the size of a full chunk of the host-to-host call (%d chunks per call, first and last half-size; copy/compute overlap)" % n_chunks,
                                                    "frames_per_launch": tm_chunk["frames"], "launch_ms": tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]),
-                                                   "frac": tm_chunk["frames"] * algorithmic_bytes_per_frame_iter(N, hop) / (tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                                   "frac": tm_chunk["frames"] * algorithmic_bytes_per_frame_iter(N, hop) * (I if tm_chunk["fast_path"] == 2 else 1) /
+                                                           (tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "whole_job_frac_resident": res_fps * per_frame_bytes / 1e9 / HBM_PEAK_GBS,
                          "whole_job_frac_host_to_host": value / world * per_frame_bytes / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,

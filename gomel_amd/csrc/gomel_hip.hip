@@ -113,7 +113,11 @@ struct gomel_handle {
     // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
     // slab of timeout words (one per live batch: the kernel's *err comes down with the waveforms, no extra round trip)
     int persist_census[3] = {-1, -1, -1};   // workgroups of k_gl_persist<Resolut, 1 | 2> / k_gl_persist_d<Resolut> the device holds at once (-1: not asked yet)
-    bool persist_off = false;     // a launch timed out once (another context held the CUs): per-iteration kernels from then on
+    // a launch timed out (another context held the CUs): per-iteration kernels for the next persist_backoff batches, then one more
+    // try; every further timeout doubles the pause (64 ... 4096 batches), so a transient neighbour costs little and a permanent one
+    // costs one 20 ms attempt in thousands of calls
+    uint64_t batches_seen = 0, persist_retry_at = 0;
+    uint32_t persist_backoff = 64;
     unsigned* err_slab = nullptr; // [kErrSlots] pinned
     std::vector<int> err_free;
     int persist_nap = 2;          // s_sleep(1) units between two looks at a slot that still shows the sentinel (GOMEL_PERSIST_NAP)
@@ -740,10 +744,11 @@ static void persist_release(gomel_batch* b) {   // the batch's launches are know
 
 // A persistent launch gave up (k_gl_persist: a workgroup waited 20 ms for a neighbour -- some other context held the CUs it
 // needed): nothing of its output is used.  x0 is still in d_x[0] (the kernel only reads it), so the batch is recomputed with the
-// per-iteration kernels, and the handle stops choosing the persistent path.  Caller holds h->mu and has synchronised the stream.
+// per-iteration kernels, and the handle pauses the persistent path (persist_backoff batches).  Caller holds h->mu and has synchronised the stream.
 static int persist_redo(gomel_batch* b, gomel_timing* tm) {
     gomel_handle* h = b->h;
-    h->persist_off = true;
+    h->persist_retry_at = h->batches_seen + h->persist_backoff;
+    h->persist_backoff = std::min<uint32_t>(h->persist_backoff * 2, 4096);
     h->err_slab[b->err_slot] = 0;
     persist_release(b);
     b->persist = 0;
@@ -1118,6 +1123,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     if (!b) return GOMEL_ERR_NO_MEMORY;
     BatchGuard guard{b};
     b->h = h; b->n_utt = n_utt; b->direct = direct; b->iters = iters;
+    h->batches_seen++;
     b->io32 = (flags & BF_IO32) ? 1 : 0; b->esz = b->io32 ? 4 : 8; b->want_spec = (flags & BF_SPEC) ? 1 : 0;
     if (b->io32 && (direct || h->precision == 64)) return GOMEL_ERR_BAD_CONFIG;   // fp32 host I/O: log-mel entry points, fp32 kernels
     b->utts.resize(n_utt); b->n_pairs.assign(n_pairs, n_pairs + n_utt);
@@ -1146,7 +1152,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         const int64_t n_wg = (b->total_frames + spw - 1) / spw;
         int max_frames = 0;
         for (const UttDesc& d : b->utts) max_frames = std::max(max_frames, d.frames);
-        const bool room = !h->persist_off && h->err_slab && !h->err_free.empty() && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20);
+        const bool room = h->batches_seen >= h->persist_retry_at && h->err_slab && !h->err_free.empty() && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20);
         if (room && !b->precise && n_wg <= persist_census(h, 2) && b->total_frames * (int64_t)N < ((int64_t)1 << 28))
             b->persist = n_wg <= persist_census(h, 1) ? 1 : 2;   // = the kernel's OCC: one wave per SIMD while the batch fits that way
         else if (room && b->precise && n_wg <= persist_census(h, 3) && b->total_frames * (int64_t)N < ((int64_t)1 << 27))

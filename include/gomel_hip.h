@@ -189,7 +189,7 @@ int gomel_batch_destroy(gomel_batch* b);
  * 3 = require the persistent kernel (gomel_batch_create fails with GOMEL_ERR_BAD_CONFIG for a batch that does not fit it).
  * The persistent kernel's workgroups wait for each other inside the launch: should another context keep them from all being
  * resident, the launch gives up after 20 ms, the batch is recomputed with the generic kernels (same results, bit for bit) and
- * the handle stops choosing that path. */
+ * the handle leaves that path alone for its next 64 batches (doubling with every further timeout, up to 4096). */
 int gomel_set_path(gomel_handle* h, int mode);
 /* Arithmetic of the Griffin-Lim iteration for batches created afterwards: 32 (default: fp32 kernels, the benchmarked path) or
  * 64 ("precise": the generic kernels in fp64 end to end, ~1e-12 from the fp64 reference arithmetic, several times slower). */

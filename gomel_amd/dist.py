@@ -23,9 +23,11 @@ def shard_bounds(frame_counts, world):
     return bounds
 
 
-def broadcast_bytes(payload, rank, world, device=None, src=0):
-    """Broadcast a bytes object from `src` (length first, then the body as a uint8 tensor on `device`)."""
-    if world == 1:
+def broadcast_bytes(payload, rank, world, device=None, src=0, force_collective=False):
+    """Broadcast a bytes object from `src` (length first, then the body as a uint8 tensor on `device`).  A world of one returns the
+    payload as it is, unless `force_collective` asks for the collective all the same (an initialised process group of one rank:
+    how a one-GPU box exercises the RCCL call path -- communicator init, uint8 CUDA broadcast -- that N ranks take)."""
+    if world == 1 and not force_collective:
         return payload
     import torch
     import torch.distributed as dist
@@ -40,16 +42,16 @@ def broadcast_bytes(payload, rank, world, device=None, src=0):
     return bytes(body.cpu().numpy().tobytes())
 
 
-def create_engine_broadcast(factory, rank, world, device=None):
+def create_engine_broadcast(factory, rank, world, device=None, force_collective=False):
     """Rank 0 builds the handle (tables computed in fp64 on its host), exports the blob, broadcasts it; the other ranks
     create their handle from the blob (gomel_create_from_tables), so every GPU clamps to bit-identical tables."""
-    if world == 1:
+    if world == 1 and not force_collective:
         return factory()
     if rank == 0:
         eng = factory()
-        broadcast_bytes(eng.export_tables(), rank, world, device)
+        broadcast_bytes(eng.export_tables(), rank, world, device, force_collective=force_collective)
         return eng
-    blob = broadcast_bytes(None, rank, world, device)
+    blob = broadcast_bytes(None, rank, world, device, force_collective=force_collective)
     return factory(tables=blob)
 
 

@@ -184,9 +184,15 @@ def _utf8_number(br):
 
 def decode(data):
     """bytes of a .flac file -> (info dict, frames) where frames is a list of per-frame lists of per-channel sample lists."""
-    if data[:4] != b"fLaC":
+    skip = 0
+    if data[:3] == b"ID3" and len(data) >= 10:               # a leading ID3v2 tag (taggers prepend them; mewkiz/flac skips it): 10-byte
+        size = 0                                             # header, 28-bit synch-safe length, optional 10-byte footer
+        for c in data[6:10]:
+            size = (size << 7) | (c & 0x7F)
+        skip = 10 + size + (10 if data[5] & 0x10 else 0)
+    if data[skip:skip + 4] != b"fLaC":
         raise FlacError("not a FLAC stream")
-    pos, info = 4, None
+    pos, info = skip + 4, None
     while True:
         if pos + 4 > len(data):
             raise FlacError("truncated metadata")
@@ -207,10 +213,15 @@ def decode(data):
         raise FlacError("no STREAMINFO block")
     frames = []
     br = _Bits(data, pos)
+    decoded = 0
     while br.byte_pos + 2 <= len(data):
         start = br.byte_pos
+        if info["total_samples"] and decoded >= info["total_samples"]:
+            break                                           # every sample STREAMINFO announces is in: what follows is not audio
         sync = br.read(15)
         if sync != 0x7FFC:
+            if frames:
+                break                                       # trailing bytes (an ID3v1 tag, padding): keep the frames decoded so far
             raise FlacError("lost frame sync at byte %d" % start)
         br.read(1)                                          # blocking strategy (only changes what the coded number counts)
         bs_code, sr_code = br.read(4), br.read(4)
@@ -255,6 +266,7 @@ def decode(data):
                 right.append((m - s) >> 1)
             sub = [left, right]
         frames.append(sub)
+        decoded += blocksize
     return info, frames
 
 

@@ -89,6 +89,10 @@ class Engine:
     def set_precision(self, bits):
         check(_lib.lib().gomel_set_precision(self._h, int(bits)), "gomel_set_precision")
 
+    def set_precision_schedule(self, fp64_iterations):
+        """The first `fp64_iterations` iterations of every call in fp64, the rest in fp32 (gomel_set_precision_schedule)."""
+        check(_lib.lib().gomel_set_precision_schedule(self._h, int(fp64_iterations)), "gomel_set_precision_schedule")
+
     def device_name(self):
         buf = ctypes.create_string_buffer(256)
         check(_lib.lib().gomel_device_name(self._h, buf, 256), "gomel_device_name")
@@ -306,7 +310,8 @@ class Batch:
         t = GomelTiming()
         check(_lib.lib().gomel_batch_run_timed(self._b, ctypes.byref(t)), "gomel_batch_run_timed")
         return {"total_ms": t.total_ms, "iter_ms": t.iter_ms, "dom_ms": t.dom_ms, "iter_launches": t.iter_launches,
-                "fast_path": t.fast_path, "frames": t.frames, "dom_kernel": ("k_gl_frames", "k_gl_fused", "k_gl_persist", "k_gl_fused_any")[t.fast_path]}
+                "fast_path": t.fast_path, "frames": t.frames, "dom64_ms": t.dom64_ms, "iter64_launches": t.iter64_launches,
+                "dom_kernel": ("k_gl_frames", "k_gl_fused", "k_gl_persist", "k_gl_fused_any")[t.fast_path]}
 
     def sync(self):
         check(_lib.lib().gomel_batch_sync(self._b), "gomel_batch_sync")
@@ -358,6 +363,7 @@ class Mel:
         self.Device = -1
         self.HannPeriodic = False
         self.Precision = 32           # 32: fp32 kernels (default); 64: fp64 "precise" mode (gomel_set_precision)
+        self.Fp64Iterations = None    # with Precision 64: only the first so many iterations in fp64, the rest fp32 (gomel_set_precision_schedule)
         self._engines = {}
 
     def _config(self):
@@ -379,10 +385,14 @@ class Mel:
                 old.close()           # one live handle per Mel object: the one being replaced is released now, not at GC time
             e = Engine(c)
             self._engines = {key: e}
-            e._precision = 32
-        if e._precision != int(self.Precision):
-            e.set_precision(int(self.Precision))
-            e._precision = int(self.Precision)
+            e._precision = (32, None)
+        want = (int(self.Precision), None if self.Fp64Iterations is None or int(self.Precision) != 64 else int(self.Fp64Iterations))
+        if e._precision != want:
+            if want[1] is None:
+                e.set_precision(want[0])
+            else:
+                e.set_precision_schedule(want[1])
+            e._precision = want
         return e
 
     # mel/mel.go:46-74

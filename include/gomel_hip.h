@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOMEL_HIP_ABI_VERSION 2
+#define GOMEL_HIP_ABI_VERSION 3
 
 typedef enum gomel_status {
     GOMEL_OK = 0,
@@ -75,6 +75,8 @@ typedef struct gomel_timing {
     int32_t fast_path;     /* 0 = generic frames + overlap-add kernels, 1 = fused sliding-window kernel, 2 = persistent kernel,
                               3 = fused kernel, any-even-hop form */
     int64_t frames;        /* frames processed                                                            */
+    float dom64_ms;        /* of dom_ms: the launches of the fp64 fused kernel (64-bit mode, precision schedule) */
+    int32_t iter64_launches; /* how many of iter_launches those were                                      */
 } gomel_timing;
 
 /* NewMel() defaults, mel/mel.go:30-41 (device = -1, symmetric Hann). */
@@ -154,7 +156,8 @@ int gomel_from_mel_batch_multi(gomel_handle* const* handles, size_t n_handles, s
 
 /* Pinned host memory for bulk callers.  gomel_from_mel_batch and friends pin pageable caller buffers for the duration of a
  * call (hipHostRegister: ~8 ms per GiB, every call); a caller that reuses its buffers allocates them here, or registers its
- * own once, and pays nothing per call.  gomel_host_unregister takes the pointer that was registered. */
+ * own once, and pays nothing per call.  gomel_host_unregister takes the pointer that was registered (a pointer it does not know:
+ * GOMEL_ERR_BAD_CONFIG); a range inside an already pinned one shares that registration and releases its share of it. */
 void* gomel_host_alloc(size_t bytes);
 int gomel_host_free(void* p);
 int gomel_host_register(void* p, size_t bytes);
@@ -194,6 +197,14 @@ int gomel_set_path(gomel_handle* h, int mode);
 /* Arithmetic of the Griffin-Lim iteration for batches created afterwards: 32 (default: fp32 kernels, the benchmarked path) or
  * 64 ("precise": the generic kernels in fp64 end to end, ~1e-12 from the fp64 reference arithmetic, several times slower). */
 int gomel_set_precision(gomel_handle* h, int bits);
+/* Precision schedule, the parity mode at a lower price: the first `fp64_iterations` Griffin-Lim iterations of every call run the
+ * fp64 kernels, the remaining ones the fp32 kernels (the signal is rounded to fp32 once, at the hand-over).  Griffin-Lim on a
+ * spectrogram that is not consistent amplifies a rounding-level perturbation by every iteration that FOLLOWS it
+ * (mel/mel.go:85-136 is not a contraction there), so fp32 rounding only in the last iterations stays near 1e-7 where fp32
+ * throughout can end 1e-4 away from the reference's float64 arithmetic.  0 = fp32 throughout
+ * (= gomel_set_precision(h, 32)); negative, or not below the call's iteration count = fp64 throughout (= 64).  Applies to the
+ * batches the fused kernel takes; smaller batches and the generic frame lengths run fp64 throughout under any schedule. */
+int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations);
 
 /* (*Mel).ToMel, mel/mel.go:46-74 = pad + gossp STFT + |S[j]|,|S[N-1-j]| + domel + ln(max(v,1e-5)). */
 size_t gomel_to_mel_pairs(const gomel_config* cfg, size_t n_samples);

@@ -19,6 +19,8 @@ for k, v in dict(G, GriffinLimIterations=I).items():
 e = m.engine()
 if os.environ.get("GOMEL_PATH"):
     e.set_path(int(os.environ["GOMEL_PATH"]))
+if os.environ.get("GOMEL_FP64_ITERS"):                            # precision schedule: -1 = fp64 throughout (k_gl_fused_d), k = first k iterations
+    e.set_precision_schedule(int(os.environ["GOMEL_FP64_ITERS"]))
 rng = np.random.default_rng(0)
 base = rng.uniform(np.log(1e-5), np.log(50.0), size=(F * m.NumMels, 2))
 b = gomel_amd.Batch(e, [F * m.NumMels] * U)

@@ -93,6 +93,28 @@ def test_loadflac_follows_the_reference_quirks(tmp_path):
     assert len(gomel_amd.LoadFlac(str(tmp_path / "missing.flac"))) == 0
 
 
+def test_leading_id3v2_tag_and_trailing_bytes(tmp_path):
+    """Files taggers have touched: an ID3v2 block in front of `fLaC`, an ID3v1 tag / padding behind the last frame.  mewkiz/flac (the
+    reference's decoder, mel/impl.go:266-296) reads them; the frames decoded before the trailing bytes are kept."""
+    from gomel_amd import codec, flac
+    a = _sig(512, 11, 12000)
+    body = fw.stream([fw.frame([a[:256]], 16, 0, "independent", [dict(kind="fixed", order=2, porder=1)]),
+                      fw.frame([a[256:]], 16, 1, "independent", [dict(kind="fixed", order=1, porder=0)])], 44100, 1, 16, 512, blocksize=256)
+    want = np.array(a, dtype=np.float64) / 65536.0
+    id3v2 = b"ID3\x04\x00\x00" + bytes([0, 0, 1, 5]) + b"\x00" * 133          # synch-safe size 1 << 7 | 5 = 133
+    id3v1 = b"TAG" + b"\x00" * 125
+    for name, data in (("tagged.flac", id3v2 + body), ("trailing.flac", body + id3v1), ("both.flac", id3v2 + body + b"\x00" * 4096)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        out, sr = codec.loadflac(str(p))
+        assert sr == 44100.0 and np.array_equal(out, want), name
+    # no total_samples in STREAMINFO (streamed encodes): the trailing bytes end the decode at the first non-frame
+    info, frames = flac.decode(fw.stream([fw.frame([a[:256]], 16, 0, "independent", [dict(kind="fixed", order=2, porder=1)])], 44100, 1, 16, 0, blocksize=256) + id3v1)
+    assert info["total_samples"] == 0 and frames == [[a[:256]]]
+    with pytest.raises(flac.FlacError):
+        flac.decode(b"ID3\x04\x00\x00\x00\x00\x00\x02xxRIFF")                # an ID3 tag in front of something that is not FLAC
+
+
 @pytest.mark.gpu
 def test_to_mel_flac_pipeline(tmp_path, oracle):
     """(*Mel).ToMelFlac, mel/mel.go:176-192: loadflac -> ToMel -> dumpimage; an unreadable file is ErrFileNotLoaded."""

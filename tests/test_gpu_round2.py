@@ -14,6 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RMS_TOL = 1e-4          # north_star: sample-for-sample within 1e-4 RMS
+PARITY_SCHEDULE = 30    # gomel_set_precision_schedule: iterations run in fp64 before the fp32 kernel takes over (bench.py's `precise.schedule`)
 
 T = dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096)     # towav geometry (cmd/towav/main.go:30-37)
 S = dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024)        # BASELINE configs[3], the TTS geometry
@@ -41,9 +42,10 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
     """BASELINE configs[2] (256 x 192 mels x 400 frames, N 4096 / hop 1280, 60 iterations): ALL 256 utterances against the C
     restatement of mel.go:76-152, true fp64 x0 on both sides.
 
-    64-bit mode must match everywhere (it does to ~1e-13: same arithmetic, two implementations).
+    The PARITY modes carry hard assertions on every utterance: 64-bit mode must match everywhere (it does to ~1e-13: same
+    arithmetic, two implementations), the precision schedule (fp64 first, fp32 last) must stay under the north-star's 1e-4.
 
-    The fp32 kernels (the benchmarked default) are checked against what the arithmetic can promise on THESE inputs.  iid-random
+    The plain fp32 kernels (the throughput default) get a STATISTICAL check -- what the arithmetic can promise on THESE inputs.  iid-random
     log-mel is not the spectrogram of any signal: Griffin-Lim does not converge on it (after 60 iterations every hop block still
     moves by ~1e-2 of the signal per iteration, spectral convergence 0.46) and the map has locally unstable directions, so a
     perturbation of one part in 1e7 -- fp32 rounding, or rounding the INPUT magnitudes to fp32 -- grows by 1.1-1.4x per iteration
@@ -62,7 +64,10 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
     eng = m.engine()
 
     def run(bits):
-        eng.set_precision(bits)
+        if bits == "schedule":
+            eng.set_precision_schedule(PARITY_SCHEDULE)
+        else:
+            eng.set_precision(bits)
         b = gomel_amd.Batch(eng, [F * K] * U)
         b.upload(mels, None, seeds)
         b.run()
@@ -77,6 +82,12 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
     e64 = np.array([rms(a - w) for a, w in zip(o64, want)])
     print("config 3, 64-bit mode vs oracle: max %.2e" % e64.max())
     assert e64.max() < 1e-9
+    # the precision schedule (first PARITY_SCHEDULE iterations fp64, the rest fp32): HARD bar on every utterance
+    osch = run("schedule")
+    esch = np.array([rms(a - w) for a, w in zip(osch, want)])
+    print("config 3, schedule (%d fp64 + %d fp32 iterations) vs oracle: median %.2e p99 %.2e max %.2e" % (
+        PARITY_SCHEDULE, 60 - PARITY_SCHEDULE, np.median(esch), np.percentile(esch, 99), esch.max()))
+    assert esch.max() < RMS_TOL, (esch.max(), int(np.argmax(esch)))
     o32 = run(32)
     e32 = np.array([rms(a - w) for a, w in zip(o32, want)])
     sig = np.array([rms(w) for w in want])
@@ -111,29 +122,46 @@ def test_config2_full_size_single_utterance_automatic_path(oracle, coracle):
 
 
 def test_config4_full_size_tts_batch(oracle, coracle):
-    """BASELINE configs[3]: 256 x 400 frames at N 1024 / hop 256 / 80 mels, 60 iterations: run-to-run determinism of the whole
-    batch, the fused and the generic kernels against each other, and utterances 0, 100 and 255 against the oracle."""
+    """BASELINE configs[3]: 256 x 400 frames at N 1024 / hop 256 / 80 mels, 60 iterations, ALL 256 utterances against the C
+    oracle: run-to-run determinism of the whole batch; hard assertions for the parity modes (64-bit: 1e-9, precision schedule:
+    the north-star's 1e-4, every utterance); the statistical check for the plain fp32 kernels (as at config 3)."""
     import gomel_amd
     fields = dict(S, GriffinLimIterations=60)
     U, F, K = 256, 400, 80
     mels, seeds = cfg3_inputs(U, F, K)
     m = mel_obj(fields)
     eng = m.engine()
-    b = gomel_amd.Batch(eng, [F * K] * U)
-    b.upload(mels, None, seeds)
-    b.run()
-    o1 = b.download()
-    b.run()
-    o2 = b.download()
-    b.close()
-    assert all(np.array_equal(a, c) for a, c in zip(o1, o2))
     cfg = oracle.MelConfig(**fields)
     L = oracle.out_len(cfg, F * K)
-    pick = [0, 100, 255]
-    want, _ = coracle.from_mel_batch(cfg, [mels[u] for u in pick], [oracle.x0_splitmix(seeds[u], L) for u in pick], threads=3)
-    for u, w in zip(pick, want):
-        print("config 4 utterance %d vs oracle: %.2e" % (u, rms(o1[u] - w)))
-        assert rms(o1[u] - w) < RMS_TOL
+    want, _ = coracle.from_mel_batch(cfg, mels, [oracle.x0_splitmix(s, L) for s in seeds], threads=min(16, os.cpu_count() or 1))
+
+    def run(mode):
+        if mode == "schedule":
+            eng.set_precision_schedule(PARITY_SCHEDULE)
+        else:
+            eng.set_precision(mode)
+        b = gomel_amd.Batch(eng, [F * K] * U)
+        b.upload(mels, None, seeds)
+        b.run()
+        o1 = b.download()
+        b.run()
+        o2 = b.download()
+        b.close()
+        assert all(np.array_equal(a, c) for a, c in zip(o1, o2))               # run-to-run bitwise
+        return np.array([rms(a - w) for a, w in zip(o1, want)])
+
+    e64 = run(64)
+    print("config 4, 64-bit mode vs oracle: max %.2e" % e64.max())
+    assert e64.max() < 1e-9
+    esch = run("schedule")
+    print("config 4, schedule (%d fp64 + %d fp32 iterations) vs oracle: median %.2e p99 %.2e max %.2e" % (
+        PARITY_SCHEDULE, 60 - PARITY_SCHEDULE, np.median(esch), np.percentile(esch, 99), esch.max()))
+    assert esch.max() < RMS_TOL, (esch.max(), int(np.argmax(esch)))
+    e32 = run(32)
+    over = np.flatnonzero(e32 > RMS_TOL)
+    print("config 4, fp32 kernels vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e, over 1e-4: %s" % (
+        np.median(e32), np.percentile(e32, 90), np.percentile(e32, 99), e32.max(), over.tolist()))
+    assert np.median(e32) < 1e-5 and np.percentile(e32, 90) < 5e-5 and len(over) <= max(1, U // 100) + 1, over   # statistical (DESIGN.md section 2)
 
 
 # ------------------------------------------------------------------------------------------------ new entry points
@@ -450,9 +478,14 @@ def test_any_frame_length_from_mel_to_mel_istft(oracle, N, hop, K, fmax):
     rng = np.random.default_rng(N)
     spec = rng.uniform(0.1, 2.0, size=(5, N)) * np.exp(2j * np.pi * rng.uniform(size=(5, N)))
     xi = oracle.x0_splitmix(2, N + 4 * hop)
-    wanti = oracle.istft_griffin_lim(s.Window, hop, spec.copy(), 2, xi)
-    goti = gomel_amd.ISTFT(s, [list(r) for r in spec], 2, x0=xi)               # (a list: no write-back requested of the generic path)
+    want_spec = spec.copy()
+    wanti = oracle.istft_griffin_lim(s.Window, hop, want_spec, 2, xi)          # (mutates want_spec, as the reference does, mel/mel.go:98-108)
+    goti = gomel_amd.ISTFT(s, [list(r) for r in spec], 2, x0=xi)               # a list cannot be written to: plain gomel_istft
     assert rms(goti - wanti) < 1e-9 * max(1.0, rms(wanti))
+    arr = spec.copy()                                                          # a complex128 ndarray: the same data, same waveform, PLUS the write-back
+    gota = gomel_amd.ISTFT(s, arr, 2, x0=xi)
+    assert np.array_equal(gota, goti)
+    assert np.max(np.abs(arr - want_spec)) < 1e-9 * np.max(np.abs(want_spec))
 
 
 # ------------------------------------------------------------------------------------------------ two processes, one GPU, real engines

@@ -1,0 +1,193 @@
+"""GPU tests added in round 3: a plain C caller that drives the GPU entry points in the cgo shim's exact order, the RCCL call path
+on a process group of one rank, a per-GPU shard of BASELINE configs[4] on one GPU, and the parity mode (gomel_set_precision)
+held to the north-star tolerance on EVERY utterance of configs[2] and configs[3]."""
+import math
+import os
+import shutil
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RMS_TOL = 1e-4          # north_star: sample-for-sample within 1e-4 RMS
+
+T = dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096)     # towav geometry (cmd/towav/main.go:30-37)
+S = dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024)        # BASELINE configs[3], the TTS geometry
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a))))
+
+
+def mel_obj(fields, **kw):
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    for k, v in dict(fields, **kw).items():
+        setattr(m, k, v)
+    return m
+
+
+def cfg3_inputs(U, F, K, first=0):
+    mels = [np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
+    return mels, [1000 + first + u for u in range(U)]
+
+
+# ------------------------------------------------------------------------------------------------ the cgo shim minus Go
+def test_c_program_drives_the_gpu_entry_points_like_the_cgo_shim(oracle, tmp_path):
+    """tests/c_gpu_caller.c = bindings/go/mel/mel_hip.go:175-205 (FromMel) and :264-317 (FromMelBatch) without Go: gomel_out_len,
+    caller-drawn x0, gomel_from_mel, then gomel_from_mel_batch with C-allocated pointer arrays and out_cap = NULL, then the exp
+    side effect.  Built as strict C99 with gcc; utterance 0 is the golden `towav_n4096_i60` case (mel/mel.go:142-152)."""
+    from gomel_amd import _lib
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_gpu_caller")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_gpu_caller.c"), "-o", exe, "-L", libdir, "-lgomel_hip", "-lm", "-Wl,-rpath," + libdir], check=True)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    fields = dict(T, GriffinLimIterations=60)
+    cfg = oracle.MelConfig(**fields)
+    F, K, U = 4, 192, 3
+    mels = [oracle.random_logmel(F, K, seed=7 + u) for u in range(U)]         # utterance 0: tests/golden/make_golden.py "towav_n4096"
+    L = oracle.out_len(cfg, F * K)
+    x0s = [oracle.x0_splitmix(8 + u, L) for u in range(U)]
+    with open(tmp_path / "in.bin", "wb") as f:
+        for m, x in zip(mels, x0s):
+            f.write(np.ascontiguousarray(m, dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(x, dtype=np.float64).tobytes())
+    r = subprocess.run([exe, "192", "16000", "1280", "4096", "60", str(F * K), str(U), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "c gpu caller ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    out = np.fromfile(tmp_path / "out.bin", dtype=np.float64)
+    assert out.size == L * (1 + U) + F * K * 2
+    single, batch, slice0 = out[:L], out[L:L * (1 + U)].reshape(U, L), out[L * (1 + U):]
+    want0 = gold["towav_n4096_i60_wave"]
+    print("C caller: gomel_from_mel vs golden %.2e, gomel_from_mel_batch[0] vs golden %.2e" % (rms(single - want0), rms(batch[0] - want0)))
+    assert rms(single - want0) < RMS_TOL and rms(batch[0] - want0) < RMS_TOL
+    for u in range(1, U):
+        assert rms(batch[u] - oracle.from_mel(cfg, mels[u].copy(), x0s[u])) < RMS_TOL
+    assert np.allclose(slice0, np.exp(mels[0]).ravel(), rtol=4e-16, atol=0.0)  # the caller's slice ends exp'd (mel/mel.go:143); libm's exp vs NumPy's: last ulp
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on a group of one rank
+def _nccl_world1_main(port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import gomel_amd
+    import gomel_oracle as go
+    from gomel_amd import dist as gd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port, device_id=dev)   # bench.py's init
+    try:
+        m = gomel_amd.NewMel()
+        for k, v in dict(S, GriffinLimIterations=4).items():
+            setattr(m, k, v)
+        m.Device = 0
+        eng = gd.create_engine_broadcast(lambda tables=None: gomel_amd.Engine(m._config(), tables=tables), 0, 1, device=dev, force_collective=True)
+        blob = gd.broadcast_bytes(eng.export_tables(), 0, 1, device=dev, force_collective=True)   # what a rank > 0 receives
+        eng2 = gomel_amd.Engine(m._config(), tables=blob)
+        mels = [go.random_logmel(f, 80, seed=i) for i, f in enumerate([30, 7, 64])]
+        a = eng.from_mel_batch(mels, None, [0, 1, 2])
+        b = eng2.from_mel_batch(mels, None, [0, 1, 2])
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)                                 # bench.py's MAX over ranks
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [None]
+        dist.all_gather_object(gathered, 3.5)
+        dist.barrier()
+        q.put(("ok", blob == eng.export_tables(), all(np.array_equal(x, y) for x, y in zip(a, b)), float(t.item()), gathered, dist.get_backend()))
+        eng.close(); eng2.close()
+    except Exception as ex:  # noqa: BLE001
+        q.put(("error", repr(ex)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_table_broadcast_through_rccl_on_a_group_of_one_rank():
+    """the one collective of the path is the broadcast of the table blob over RCCL.  One GPU cannot show N ranks, but it
+    can run the SAME call path once: torch.distributed with the nccl backend (= RCCL) and device_id, a uint8 CUDA-tensor broadcast
+    that is forced through the collective (dist.broadcast_bytes short-circuits a world of one otherwise), the float64 all_reduce(MAX)
+    and all_gather_object bench.py uses -- and a handle built from the bytes that came back computes the same bits."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_main, args=(port, q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert got[0] == "ok", got
+    assert p.exitcode == 0
+    _, same_blob, same_bits, tmax, gathered, backend = got
+    assert backend == "nccl" and same_blob and same_bits and tmax == 1.25 and gathered == [3.5]
+
+
+# ------------------------------------------------------------------------------------------------ cmd/towav counterpart
+def test_towav_command_line(tmp_path, capsys):
+    """`python -m gomel_amd.towav <png> [rate]` = cmd/towav/main.go:10-47: fixed towav parameters, <png>.wav beside the input, the
+    usage line and exit code 1 without an argument, the error line and exit code 1 for a file that does not load."""
+    from gomel_amd import towav
+    png = str(tmp_path / "in.png")
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "chirp_192.png"), png)
+    assert towav.main(["towav", png, "22050"]) == 0
+    raw = open(png + ".wav", "rb").read()
+    assert raw[:4] == b"RIFF" and int.from_bytes(raw[24:28], "little") == 22050            # the rate given on the command line wins (main.go:39)
+    assert (len(raw) - 44) // 2 == 4096 + 38 * 1280                                        # 39 frames, mono 16-bit
+    assert towav.main(["towav"]) == 1 and "Usage" in capsys.readouterr().out
+    assert towav.main(["towav", str(tmp_path / "missing.png")]) == 1
+    assert "Error generating wave from spectrogram: wavNotLoaded" in capsys.readouterr().out
+
+
+# ------------------------------------------------------------------------------------------------ precision schedule
+@pytest.mark.parametrize("fields,frames", [(S, [60, 33, 47, 64, 12, 90]), (T, [40, 25, 64]), (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), [50, 70])])
+def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
+    """gomel_set_precision_schedule(h, k): the first k iterations in fp64 (k_gl_fused_d), the signal handed over once (tails folded
+    in, rounded to fp32), the remaining iterations in fp32 (k_gl_fused).  That is exactly: a 64-bit call of k iterations, then an
+    fp32 call of I - k iterations started from its output -- bit for bit.  Outside the fused kernel's batches (here: the same
+    batch on the generic kernels) a schedule runs fp64 throughout, and the degenerate schedules are the plain modes."""
+    import gomel_amd
+    I, k = 7, 3
+    K = fields["NumMels"]
+    mels = [oracle.random_logmel(f, K, seed=40 + i) for i, f in enumerate(frames)]
+    seeds = list(range(len(frames)))
+
+    def run(iters, sched, path, x0s=None):
+        m = mel_obj(fields, GriffinLimIterations=iters)
+        e = m.engine()
+        e.set_path(path)
+        e.set_precision_schedule(sched)
+        b = gomel_amd.Batch(e, [len(mm) for mm in mels])
+        b.upload(mels, x0s, seeds)
+        tm = b.run_timed()
+        out = b.download()
+        b.close(); e.close()
+        return out, tm
+
+    mixed, tm = run(I, k, 2)
+    assert tm["iter_launches"] == I and tm["iter64_launches"] == k and tm["fast_path"] == 1, tm
+    first, tm1 = run(k, -1, 2)                                  # k iterations, fp64 throughout
+    assert tm1["iter64_launches"] == k
+    second, tm2 = run(I - k, 0, 2, x0s=first)                   # I - k iterations, fp32 throughout, from there
+    assert tm2["iter64_launches"] == 0
+    assert all(np.array_equal(a, b) for a, b in zip(mixed, second))
+    cfg = oracle.MelConfig(GriffinLimIterations=I, **fields)
+    for i in (0, len(frames) - 1):
+        want = oracle.from_mel(cfg, mels[i].copy(), oracle.x0_splitmix(seeds[i], len(mixed[i])))
+        assert rms(mixed[i] - want) < 1e-5
+    all64, tm64 = run(I, -1, 2)
+    same, tms = run(I, I, 2)                                    # a schedule that covers every iteration is 64-bit mode
+    assert tms["iter64_launches"] == I and all(np.array_equal(a, b) for a, b in zip(all64, same))
+    gen64, _ = run(I, -1, 1)
+    gens, tmg = run(I, k, 1)                                    # generic kernels: no schedule, fp64 throughout
+    assert tmg["iter64_launches"] == 0 and tmg["fast_path"] == 0 and all(np.array_equal(a, b) for a, b in zip(gen64, gens))
+    assert max(rms(a - b) for a, b in zip(gen64, all64)) < 1e-12

@@ -18,8 +18,8 @@ on the library's stream in this run, its algorithmic bytes from SURVEY 8(d).
 Workloads (BASELINE.json configs): cfg3 = configs[2], 256 x (192 mels x 400 frames) random log-mel, N 4096 / hop 1280, 60
 iterations (the configuration the roofline figure is quoted on; default at N = 1, weak scaling when forced at N > 1).  cfg5 =
 configs[4], a FIXED corpus of 8192 such utterances cut into one contiguous shard per rank (strong scaling; default when N > 1); a
-rank materialises its shard as one 256-utterance host block that is re-used with the shard's own seeds (synthetic data), one call
-per block.  cfg2 = configs[1], one 10 s utterance (342 frames), also reported in every N = 1 line as `single_utterance`.  cfg4 =
+rank holds a shard of up to 1024 utterances whole on the host (8 GPUs: 1024 per rank; a larger shard re-uses one 256-utterance host
+block with the shard's own seeds), one call per block of 256.  cfg2 = configs[1], one 10 s utterance (342 frames), also reported in every N = 1 line as `single_utterance`.  cfg4 =
 configs[3], the 22.05 kHz TTS geometry (N 1024 / hop 256 / 80 mels).  Utterances are independent: no data-path collective; the
 one collective is the broadcast of the table blob ("mel basis") from rank 0 over RCCL.
 Prints ONE JSON line on rank 0.
@@ -51,6 +51,7 @@ WORKLOADS = {
 }
 STRONG = {"cfg5"}
 BLOCK = 256                     # utterances per gomel_from_mel_batch call
+MATERIALISE = 1024              # shards up to this many utterances are materialised whole on the host (configs[4] at 8 GPUs: 1024 per rank)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PARITY_SCHEDULE = 30            # iterations in fp64 before the fp32 kernel takes over (gomel_set_precision_schedule), see DESIGN.md section 2
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
@@ -132,14 +133,18 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     import torch
     K = fields["NumMels"]
     nb = min(BLOCK, n_local)
+    # a shard of up to MATERIALISE utterances is held whole (every utterance its own data and buffers, 5.4 MB each at the towav
+    # geometry); a larger one re-uses one block of BLOCK utterances' buffers with the shard's own seeds
+    whole = n_local <= MATERIALISE
+    nmat = n_local if whole else nb
     alloc = gomel_amd.host_alloc if pinned else (lambda shape, dtype=np.float64: np.zeros(shape, dtype=dtype))
     mels = []
-    for u, src in enumerate(make_inputs(fields, nb, frames, first)):
+    for u, src in enumerate(make_inputs(fields, nmat, frames, first)):
         a = alloc((frames * K, 2))
         a[:] = src
         mels.append(a)
     L = engine.out_len(frames * K)
-    outs = [alloc(L) for _ in range(nb)]
+    outs = [alloc(L) for _ in range(nmat)]
     for o in outs:
         o[:] = 0.0                                                   # touched: what a caller's own slices are
     blocks = [(b0, min(nb, n_local - b0)) for b0 in range(0, n_local, nb)]
@@ -147,7 +152,8 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     def step():
         for b0, cnt in blocks:
             seeds = [1000 + first + b0 + u for u in range(cnt)]      # the seed of an utterance is its GLOBAL index
-            engine.from_mel_batch(mels[:cnt], None, seeds, outs[:cnt])
+            m0 = b0 if whole else 0
+            engine.from_mel_batch(mels[m0:m0 + cnt], None, seeds, outs[m0:m0 + cnt])
 
     for _ in range(warmup):
         step()
@@ -160,7 +166,8 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     barrier()
     elapsed = time.perf_counter() - t0
     last_b0, last_cnt = blocks[-1]
-    return elapsed, mels[:last_cnt], [1000 + first + last_b0 + u for u in range(last_cnt)], [np.array(o) for o in outs[:last_cnt]]
+    m0 = last_b0 if whole else 0
+    return elapsed, mels[m0:m0 + last_cnt], [1000 + first + last_b0 + u for u in range(last_cnt)], [np.array(o) for o in outs[m0:m0 + last_cnt]]
 
 
 def resident(engine, fields, n_utt, frames, first, steps):

@@ -221,7 +221,7 @@ func ISTFT(s *stft.STFT, spectrogram [][]complex128, numIterations int) []float6
 	if rc := C.gomel_set_window(h, (*C.double)(unsafe.Pointer(&s.Window[0])), C.size_t(len(s.Window))); rc != C.GOMEL_OK {
 		panic(statusErr(rc))
 	}
-	half := frameLen/2 + 1
+	half := frameLen/2 + 1 + frameLen%2 // C.gomel_istft_row_len: an odd frameLen keeps bins N/2 and N/2+1 (mel.go:105 fills N-1 ... N/2+2 only)
 	mags := make([]float64, numFrames*half)
 	for i := range spectrogram {
 		for j := 0; j < half; j++ {

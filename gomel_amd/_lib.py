@@ -44,6 +44,7 @@ SYMBOLS = {
     "gomel_out_len": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
     "gomel_from_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_uint64, c_double_p,
                                       ctypes.c_size_t, c_size_p]),
+    "gomel_istft_row_len": (ctypes.c_size_t, [_cfg_p]),
     "gomel_istft": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, ctypes.c_int32, c_double_p, ctypes.c_uint64, c_double_p,
                                    ctypes.c_size_t, c_size_p]),
     "gomel_istft_spec": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, ctypes.c_int32, c_double_p, ctypes.c_uint64, c_double_p,

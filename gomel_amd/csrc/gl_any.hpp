@@ -89,14 +89,15 @@ __device__ __forceinline__ v2d unit_phase_any(v2d x) {   // cmplx.Phase(0) = 0 -
 
 // One Griffin-Lim iteration for one frame (MODE kAnyGl): x -> windowed frame -> DFT -> clamp -> IDFT -> windowed frame yw[frame][N];
 // or the STFT magnitudes of ToMel (kAnyToMel): |S[k]|, k = 0 ... N/2 -> smag[frame][N/2+1]; or ISTFT's side effect on its
-// spectrogram argument (kAnySpec, mel/mel.go:98-102): Rect(|spectrogram[i][k]|, Phase(S[k])), k = 0 ... N/2 ->
-// spec[frame][N/2+1] complex (what the clamp step of an iteration on x leaves in those bins; the shim mirrors the rest).
+// spectrogram argument (kAnySpec, mel/mel.go:98-102): Rect(|spectrogram[i][k]|, Phase(S[k])) for the bins that keep a magnitude of
+// their own, k = 0 ... N/2 (odd N: ... N/2+1) -> spec[frame][that many] complex (what the clamp step of an iteration on x leaves
+// in those bins; the shim mirrors the rest).
 constexpr int kAnyGl = 0, kAnyToMel = 1, kAnySpec = 2;
 template <int MODE>
 __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __restrict__ x, const int64_t* __restrict__ frame_xoff,
                                                             const double* __restrict__ mag, const double* __restrict__ nyq,
                                                             double* __restrict__ out, int64_t n_frames, int N,
-                                                            const double* __restrict__ window, AnyTables at) {
+                                                            const double* __restrict__ window, AnyTables at, const double* __restrict__ mid = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char any_smem[];
     v2d* buf = reinterpret_cast<v2d*>(any_smem);
     const int64_t frame = blockIdx.x;
@@ -120,9 +121,10 @@ __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __rest
     const int own_top = odd ? H + 1 : H;                 // highest bin that keeps a magnitude of its own
     for (int k = threadIdx.x; k <= own_top; k += kAnyThreads) {
         const int p = pos(k);
-        const double m = k < H ? mag[frame * H + k] : (k == own_top ? nyq[frame] : 0.0);
+        // (odd N, bin H: nothing of a log-mel input lands there; the exported ISTFT's spectrogram has a magnitude for it -- `mid`)
+        const double m = k < H ? mag[frame * H + k] : (k == own_top ? nyq[frame] : (mid ? mid[frame] : 0.0));
         const v2d u = unit_phase_any(buf[p]);
-        if (MODE == kAnySpec) { if (k <= H) reinterpret_cast<v2d*>(out)[frame * (H + 1) + k] = v2d{u.x * m, u.y * m}; }
+        if (MODE == kAnySpec) reinterpret_cast<v2d*>(out)[frame * (own_top + 1) + k] = v2d{u.x * m, u.y * m};
         else buf[p] = v2d{u.x * m, u.y * m};
     }
     if (MODE == kAnySpec) return;

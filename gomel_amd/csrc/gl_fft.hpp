@@ -606,7 +606,8 @@ GL_DEV long long uniform_i64(long long v) {
 }
 // The eight W_N^{k_s} of a lane from ONE table value: k_s = t + B3*s and N/B3 = 16, so W_N^{k_s} = W_N^t * W_16^s (lane 0's
 // permuted slots get their constants).  Costs a few multiplies per frame, saves 14 registers in the fused kernel.
-template <class G> GL_DEV void make_wn(v2f (&w)[8], int t, v2f wt) {
+template <class G, class V> GL_DEV void make_wn(V (&w)[8], int t, V wt) {
+    typedef typename ScalarOf<V>::type S;
     constexpr double c16[8] = {1.0, kC1, kS2, kS1, 0.0, -kS1, -kS2, -kC1};
     constexpr double s16[8] = {0.0, kS1, kS2, kC1, 1.0, kC1, kS2, kS1};
     // W_32^{1,3,5,7} = cos/sin(pi m/16)
@@ -615,8 +616,8 @@ template <class G> GL_DEV void make_wn(v2f (&w)[8], int t, v2f wt) {
     const bool is0 = (t == 0);
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-        v2f g = twc<false>(wt, c16[s], s16[s]);  // wt * W_16^s
-        v2f z = s == 0 ? v2f{0.f, -1.f} : (s < 4 ? v2f{(float)c16[s], (float)-s16[s]} : v2f{(float)c32[s - 4], (float)-s32[s - 4]});
+        V g = twc<false>(wt, c16[s], s16[s]);  // wt * W_16^s
+        V z = s == 0 ? V{(S)0, (S)-1} : (s < 4 ? V{(S)c16[s], (S)-s16[s]} : V{(S)c32[s - 4], (S)-s32[s - 4]});
         w[s] = is0 ? z : g;
     }
 }

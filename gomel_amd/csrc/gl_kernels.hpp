@@ -187,11 +187,17 @@ __global__ __launch_bounds__(256) void k_mel_to_mag_nat(const double* __restrict
         if (k == H - 1) nyq[f] = fabs((apply_row_exp(r, m, 1) - tune_add) / tune_mul);              // channel 1's last bin lands on bin N/2
     }
 }
-__global__ __launch_bounds__(256) void k_mag_direct_nat(const double* __restrict__ in, double* __restrict__ mag, double* __restrict__ nyq, int H) {
+// (odd N = 2H+1: rows of H+2 magnitudes -- bins H and H+1 both lie outside the conjugate fill of mel/mel.go:105-108 and keep their
+// own: bin H goes to `mid`, bin H+1 to `nyq`, the slot of "the highest bin with a magnitude of its own")
+__global__ __launch_bounds__(256) void k_mag_direct_nat(const double* __restrict__ in, double* __restrict__ mag, double* __restrict__ nyq, double* __restrict__ mid,
+                                                        int H, int odd) {
     const int64_t f = blockIdx.x;
-    const double* m = in + f * (H + 1);
+    const double* m = in + f * (H + 1 + odd);
     for (int k = threadIdx.x; k < H; k += blockDim.x) mag[f * H + k] = fabs(m[k]);
-    if (threadIdx.x == 0) nyq[f] = fabs(m[H]);
+    if (threadIdx.x == 0) {
+        if (odd) { mid[f] = fabs(m[H]); nyq[f] = fabs(m[H + 1]); }
+        else nyq[f] = fabs(m[H]);
+    }
 }
 
 // =============================================================================================== K3: initial signal
@@ -410,6 +416,9 @@ constexpr int kFusedThreads = 256;
 constexpr int fused_w1_keep(int n, int sh) { return n >= 4096 ? (sh >= 8 ? 15 : sh >= 4 ? 11 : 0) : (n >= 2048 && sh <= 1) ? 0 : 15; }
 constexpr bool fused_late_rows(int n) { return n <= 2048; }
 constexpr bool fused_w2_regs(int n, int sh) { return !(n >= 4096 && sh <= 2); }   // hop = N/16, N/8 at N 4096: the 14-15 row accumulator leaves no room
+// One window read per frame (the synthesis multiply's registers serve the next frame's analysis multiply, k_gl_fused) costs ~30
+// registers around the loop's back edge: taken where no spill results (hipcc -S audit, tests/test_isa_hazards.py).
+constexpr bool fused_one_window_read(int n, int sh) { return n >= 4096 || (n == 2048 && sh != 2) || sh == 4 || sh == 8; }
 constexpr int kMaxSegFrames = 64;   // a wave fetches the Nyquist magnitudes of all its segment's frames with ONE load (lane = frame)
 
 // Lane-pair form of two consecutive rows.  A row is T sample pairs, one per lane (8 bytes): as such it moves with dwordx2
@@ -935,6 +944,21 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         asm volatile("v_mov_b32 %0, %0" : "+v"(nyq_all));
     }
 
+    // The window is read from LDS ONCE per frame: the synthesis multiply at the end of frame g (y * w) and the analysis multiply of
+    // frame g+1 (x * w) sit next to each other in time, so the 16 window registers loaded for the first serve the second as well,
+    // and the windowed input v crosses the loop's back edge instead of being rebuilt at the top (16 of the ~156 LDS reads of a frame,
+    // 16 KB of the ~158 KB a frame moves through the LDS: the kernel is power-limited and LDS bytes are part of the bill).
+    // (ROT: where the register file takes it without spilling -- fused_one_window_read; the other instantiations read the window twice)
+    constexpr bool ROT = fused_one_window_read(N, SH);
+    v2f v[16];
+    if constexpr (ROT) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = wl[T * j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] *= xin[j];
+    }
+
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
@@ -945,13 +969,14 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         if constexpr (T >= 64) mraw.nq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nyq_all), gg));
         else mraw.nq = nyq_p[gg + (t & 3)];
         st.mark(16);
-        v2f v[16];
-        // all 16 window reads go out back to back (one LDS round trip, not sixteen), then the multiplies
+        if constexpr (!ROT) {
+            // all 16 window reads go out back to back (one LDS round trip, not sixteen), then the multiplies
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = wl[T * j];
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 16; j++) v[j] = wl[T * j];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] *= xin[j];
+            for (int j = 0; j < 16; j++) v[j] *= xin[j];
+        }
         st.mark(17);
         // The next frame's SH new rows (hop samples), two rows per dwordx4, and -- in the last frames of a segment with a
         // successor -- the successor's head from the tail buffer (rare: behind a wave-uniform branch).  The loaded values stay RAW
@@ -1006,6 +1031,13 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         for (int jj = 0; jj < SH; jj++) asm volatile("" : "+v"(xin[KEEP + jj]));
         __builtin_amdgcn_sched_barrier(0);
         st.mark(18);
+        v2f w[16];   // the window: all 16 reads go out back to back (one LDS round trip, not sixteen)
+        if constexpr (ROT) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) w[j] = wl[T * j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto W = [&](int j) { if constexpr (ROT) return w[j]; else return wl[T * j]; };
         if (active) {
             // overlap-add in registers: row j of this frame lands on accumulator row j (rows >= KEEP start a new sum);
             // the first SH rows are finished by this frame and leave (two rows per dwordx4), the rest shift down by SH.
@@ -1013,7 +1045,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             v2f yo[SH];
 #pragma unroll
             for (int j = 0; j < SH; j++) {
-                const v2f y = v[j] * wl[T * j];
+                const v2f y = v[j] * W(j);
                 yo[j] = (j < KEEP) ? acc[j] + y : y;
             }
 #pragma unroll
@@ -1022,7 +1054,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             v2f nacc[KEEP];
 #pragma unroll
             for (int j = 0; j < KEEP; j++) {
-                const v2f y = v[j + SH] * wl[T * (j + SH)];
+                const v2f y = v[j + SH] * W(j + SH);
                 nacc[j] = (j + SH < KEEP) ? acc[j + SH] + y : y;
             }
 #pragma unroll
@@ -1037,6 +1069,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
                     for (int j = 0; j < KEEP; j++) xout_p[T * (rows_owned + j) + t] = acc[j];
                 }
             }
+        }
+        // the next frame's windowed input, with the window registers of this frame's synthesis
+        if constexpr (ROT) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = w[j] * xin[j];
         }
         st.mark(14);
     }
@@ -1344,7 +1381,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     }
     v2d xin[16], acc[KEEP], wn[8];
     const v2d* wl = win_l + t;
-    load_wn<G>(wn, t, tb.wnd);
+    load_wn<G>(wn, t, tb.wnd);   // (rebuilt per frame from one table value, as make_wn does for the fp32 kernel: +3 % vector instructions here)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         v2d a = xin_p[T * j + t];
@@ -1362,6 +1399,8 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
         MagRawD mraw;                                                         // issued now, finished after the forward FFT
         load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
         mraw.nq = nyq_p[gg];
+        // (k_gl_fused's single window read per frame was tried here too: 64 more live registers around the back edge, 3 % MORE
+        // vector instructions through the AGPR traffic they cause -- the window is read twice)
         v2d v[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = wl[T * j] * xin[j];

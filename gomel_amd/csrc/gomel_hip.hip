@@ -495,6 +495,7 @@ struct gomel_batch {
     double* d_nyqd = nullptr;
     double* d_xd[2] = {nullptr, nullptr};
     double* d_ywd = nullptr;
+    double* d_midd = nullptr;   // exported ISTFT at an odd frame length: |spectrogram[f][N/2]| (bin N/2+1's magnitude sits in d_nyqd)
     int64_t* d_frame_xoff = nullptr;
     UttDesc* d_utts = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -515,13 +516,15 @@ struct gomel_batch {
     size_t ctl_bytes = 0;
 };
 
+// magnitudes per frame the exported ISTFT reads: bins 0 ... N/2, and bin N/2+1 as well when N is odd (both top bins lie outside the conjugate fill)
+static inline size_t istft_row(int N) { return (size_t)(N / 2 + 1 + (N & 1)); }
 static inline hipStream_t run_stream(const gomel_batch* b) { return b->rs ? b->rs : b->h->stream; }
 static void persist_release(gomel_batch* b);
 static void batch_free(gomel_batch* b) {
     if (!b) return;
     DeviceGuard dg(b->h->device);
     void* ptrs[] = {b->d_spec, b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
-                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_xd[0], b->d_xd[1], b->d_ywd,
+                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_midd, b->d_xd[0], b->d_xd[1], b->d_ywd,
                     b->d_frame_utt, b->d_ctl};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
     persist_release(b);
@@ -794,7 +797,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     } else {
         if (b->precise) {   // fp64 generic kernels end to end
             if (h->generic) {
-                if (b->direct) hipLaunchKernelGGL(k_mag_direct_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, b->d_magd, b->d_nyqd, N / 2);
+                if (b->direct) hipLaunchKernelGGL(k_mag_direct_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, b->d_magd, b->d_nyqd, b->d_midd, N / 2, N & 1);
                 else hipLaunchKernelGGL(k_mel_to_mag_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
             }
             else if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
@@ -849,7 +852,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
                 if (h->generic)
                     hipLaunchKernelGGL(glany::k_any_frames<glany::kAnyGl>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
-                                       b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, N, h->dt.windowd, h->dt.any);
+                                       b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, N, h->dt.windowd, h->dt.any, b->d_midd);
                 else
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_frames_d<NN>, dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, h->dt));
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
@@ -859,7 +862,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
             if (b->want_spec && h->generic)   // the literal form's clamp step on x_{I-1}, bins 0 ... N/2 (d_magd holds |spectrogram| as the caller gave it)
                 hipLaunchKernelGGL(glany::k_any_frames<glany::kAnySpec>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
-                                   b->d_xd[curd ^ 1], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_spec, b->total_frames, N, h->dt.windowd, h->dt.any);
+                                   b->d_xd[curd ^ 1], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_spec, b->total_frames, N, h->dt.windowd, h->dt.any, b->d_midd);
             else if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
             if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
@@ -1195,7 +1198,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // consecutive frames per stream and so only pays once there are enough frames to fill the chip (fused_min_frames); in
     // between (and for hops neither takes) every frame in parallel, two launches per iteration (generic kernels).
     b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
-    if (h->generic && (b->io32 || (b->want_spec && (N & 1)))) return GOMEL_ERR_UNSUPPORTED_N;   // (the exported ISTFT at odd lengths: see istft_guarded)
+    if (h->generic && b->io32) return GOMEL_ERR_UNSUPPORTED_N;
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     // (every frame gathers its whole window from the covering frames, N/hop times the bytes of k_ola's single pass: beyond eight
     // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms
@@ -1226,9 +1229,10 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     int rc = GOMEL_OK;
     const hipStream_t ist = init_stream ? init_stream : h->stream;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
-    alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * (size_t)(N / 2 + 1) * 8 : (size_t)b->total_pairs * 2 * b->esz);
+    alloc((void**)&b->d_mel, direct ? (size_t)b->total_frames * istft_row(N) * 8 : (size_t)b->total_pairs * 2 * b->esz);
     alloc((void**)&b->d_out, (size_t)b->total_len * b->esz);
-    if (b->want_spec && I > 0) alloc((void**)&b->d_spec, (size_t)b->total_frames * (size_t)(N / 2 + 1) * 16);
+    if (b->want_spec && I > 0) alloc((void**)&b->d_spec, (size_t)b->total_frames * istft_row(N) * 16);
+    if (direct && (N & 1) && I > 0) alloc((void**)&b->d_midd, (size_t)b->total_frames * 8);
     alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
     if (I > 0 && b->precise) {
         alloc((void**)&b->d_magd, (size_t)b->total_frames * (N / 2) * 8);
@@ -1313,7 +1317,7 @@ static int batch_upload_impl(gomel_batch* b, const void* const* mel, const void*
     }
     if (b->any_x0 && !b->d_x0) HIPCHK(h->pool.alloc((void**)&b->d_x0, (size_t)b->total_len * esz));
     PinnedScope pins;
-    const size_t row = b->direct ? (size_t)(h->cfg.resolut / 2 + 1) : 2;   // elements per input unit (magnitude row / pair)
+    const size_t row = b->direct ? istft_row(h->cfg.resolut) : 2;   // elements per input unit (magnitude row / pair)
     if (pin_here)
         for (size_t u = 0; u < b->n_utt; u++) {
             pins.want(mel[u], b->n_pairs[u] * row * esz);
@@ -1498,11 +1502,11 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
     // At most three chunks hold device buffers at a time (uploading c+1, computing c, downloading c-1): chunk c-2's batch is
     // destroyed -- its buffers go back to the handle's pool -- before chunk c+1's is created, so a call of any size cycles
     // through three sets of buffers instead of allocating one per chunk.
-    // Two compute streams, the chunks alternating between them: a chunk's 60 launches are each one round of the chip, and behind
-    // one another on ONE stream every launch pays its ramp and its tail alone (a 12 800-frame launch runs 9 % below the
-    // whole-batch launch's rate, profiles/r02); with the neighbouring chunk's launches on a second stream the tail of one launch is
-    // filled by the head of the other's.  GOMEL_COMPUTE_STREAMS=1 keeps everything on one stream (A/B knob).
-    static const int n_cs = [] { const char* e = getenv("GOMEL_COMPUTE_STREAMS"); return e && atoi(e) == 1 ? 1 : 2; }();
+    // Two compute streams, the chunks alternating between them, so that the tail of one chunk's launch is filled by the head of the
+    // neighbour's: built and MEASURED in round 3 (profiles/r03/compute_streams.txt: 2.365 / 2.363 M frames/s against 2.379 / 2.390 M
+    // on one stream, config 3, interleaved runs on one box) -- the two kernels share the chip's LDS and registers rather than its idle
+    // tail.  One stream stays the default; GOMEL_COMPUTE_STREAMS=2 is the A/B knob.
+    static const int n_cs = [] { const char* e = getenv("GOMEL_COMPUTE_STREAMS"); return e && atoi(e) == 2 ? 2 : 1; }();
     if (n_cs == 2 && n_chunks > 1 && !h->stream2) {
         std::lock_guard<std::mutex> lk(h->mu);
         DeviceGuard dg(h->device);
@@ -1662,7 +1666,6 @@ static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, i
     const size_t L = (size_t)h->cfg.resolut + (n_frames - 1) * (size_t)h->cfg.window;   // mel/mel.go:80
     if (out_cap < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
     gomel_batch* b = nullptr;
-    if (h->cfg.resolut & 1) return GOMEL_ERR_UNSUPPORTED_N;   // odd N: bins N/2 AND N/2+1 keep magnitudes of their own in the exported ISTFT; the [N/2+1] interface cannot carry both
     const bool spec = spec_out && iterations > 0;   // zero iterations: the loop never runs, the spectrogram is left as it was
     int rc = batch_create_common(h, 1, &n_frames, BF_DIRECT | (spec ? BF_SPEC : 0), iterations, &b);
     if (rc) return rc;
@@ -1675,7 +1678,7 @@ static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, i
         if (!rc) rc = batch_upload_impl(b, ins, x0s, &seed, true, true, h->stream);
         if (!rc) rc = batch_run_impl(b, nullptr);
         if (!rc && spec) {
-            const size_t bytes = n_frames * (size_t)(h->cfg.resolut / 2 + 1) * 16;
+            const size_t bytes = n_frames * istft_row(h->cfg.resolut) * 16;
             PinnedScope pins;
             pins.want(spec_out, bytes); pins.commit(h->stream);
             if (hipMemcpyAsync(spec_out, b->d_spec, bytes, hipMemcpyDefault, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
@@ -1690,6 +1693,7 @@ static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, i
     return rc;
 }
 
+size_t gomel_istft_row_len(const gomel_config* cfg) { return (cfg && cfg->resolut > 0) ? istft_row(cfg->resolut) : 0; }
 int gomel_rfft_frames(gomel_handle* h, const float* frames, size_t n_frames, float* spectrum) { return fft_hook(h, false, frames, n_frames, spectrum); }
 int gomel_irfft_frames(gomel_handle* h, const float* spectrum, size_t n_frames, float* frames) { return fft_hook(h, true, spectrum, n_frames, frames); }
 

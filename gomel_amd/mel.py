@@ -119,11 +119,11 @@ class Engine:
         return out[:got.value]
 
     def istft(self, magnitudes, iterations, x0=None, seed=0, spec=False):
-        """gomel_istft: Griffin-Lim from linear magnitudes [F][N/2+1] (the reference's exported ISTFT, mel/mel.go:76-139).
-        With spec=True (gomel_istft_spec) also returns what the reference leaves in its spectrogram argument, bins 0..N/2
-        (complex [F][N/2+1]; None when iterations == 0: the reference's loop does not run)."""
+        """gomel_istft: Griffin-Lim from linear magnitudes [F][N/2+1] (the reference's exported ISTFT, mel/mel.go:76-139; an odd N
+        keeps bins N/2 and N/2+1: rows of N/2+2).  With spec=True (gomel_istft_spec) also returns what the reference leaves in its
+        spectrogram argument in those bins (complex, same row length; None when iterations == 0: the reference's loop does not run)."""
         m = np.ascontiguousarray(magnitudes, dtype=np.float64)
-        H1 = self.cfg.resolut // 2 + 1
+        H1 = self.cfg.resolut // 2 + 1 + (self.cfg.resolut & 1)
         if m.ndim != 2 or m.shape[1] != H1:
             raise ValueError("magnitudes must be [frames, %d]" % H1)
         F = m.shape[0]
@@ -543,10 +543,11 @@ def ISTFT(s, spectrogram, numIterations, x0=None, seed=None, device=-1):
         if x0 is None and seed is None:
             seed = random.getrandbits(64)
         writable = isinstance(spectrogram, np.ndarray) and spectrogram.dtype == np.complex128 and spectrogram.flags.writeable
+        own = N // 2 + 1 + (N & 1)                                         # bins the conjugate fill (mel/mel.go:105-108) leaves alone
         if not writable or int(numIterations) == 0:
-            return e.istft(np.abs(spec[:, :N // 2 + 1]), numIterations, x0=x0, seed=seed or 0)
-        wave, sp = e.istft(np.abs(spec[:, :N // 2 + 1]), numIterations, x0=x0, seed=seed or 0, spec=True)
-        spectrogram[:, :N // 2 + 1] = sp                                   # mel/mel.go:98-102, bins 0 .. N/2
+            return e.istft(np.abs(spec[:, :own]), numIterations, x0=x0, seed=seed or 0)
+        wave, sp = e.istft(np.abs(spec[:, :own]), numIterations, x0=x0, seed=seed or 0, spec=True)
+        spectrogram[:, :own] = sp                                          # mel/mel.go:98-102, the bins with their own magnitude
         j = np.arange(1, N // 2)
         spectrogram[:, N - j] = np.conj(spectrogram[:, j])                 # mel/mel.go:105-108
         return wave

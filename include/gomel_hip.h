@@ -122,13 +122,16 @@ int gomel_from_mel(gomel_handle* h, const double* mel_pairs, size_t n_pairs, con
 /* ISTFT(s, spectrogram, numIterations), mel/mel.go:76-139 -- the Griffin-Lim loop itself, exported by the reference.  Of its
  * complex [F][N] argument it reads only |spectrogram[f][j]| for j <= N/2 (phases are re-estimated every iteration and the upper
  * half is conjugate-filled, mel.go:98-108), so the boundary takes those magnitudes: [n_frames][N/2+1] doubles (host or device).
+ * An ODD frame length N keeps one more bin: the fill `for j := 1; j < N/2` (mel.go:105) reaches bins N-1 ... N/2+2 only, so bins
+ * N/2 AND N/2+1 keep magnitudes of their own and the rows are N/2+2 long -- gomel_istft_row_len says which.
  * Window and hop come from the handle (gomel_set_window injects s.Window); `iterations` = numIterations >= 0 replaces the
  * handle's GriffinLimIterations for this call.  x0 / seed / out as for gomel_from_mel. */
+size_t gomel_istft_row_len(const gomel_config* cfg); /* N/2+1, or N/2+2 when Resolut is odd; 0 for a NULL cfg */
 int gomel_istft(gomel_handle* h, const double* magnitudes, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,
                 double* out, size_t out_cap, size_t* out_len);
 /* The same with ISTFT's side effect on its argument (mel/mel.go:98-108: every iteration overwrites spectrogram[i][j] with
- * Rect(Abs(spectrogram[i][j]), Phase(S[j])) and conjugate-fills the upper half): spec_out receives [n_frames][N/2+1][2] doubles,
- * bins 0 ... N/2 of what the reference leaves in the caller's slice -- the last iteration's phase estimate on the caller's
+ * Rect(Abs(spectrogram[i][j]), Phase(S[j])) and conjugate-fills the upper half): spec_out receives [n_frames][row_len][2] doubles
+ * (row_len = gomel_istft_row_len: N/2+1, odd N: N/2+2), the bins that keep their own magnitude, of what the reference leaves in the caller's slice -- the last iteration's phase estimate on the caller's
  * magnitudes; the Go shim writes them back and mirrors bins N/2+1 ... N-1 as conjugates.  Nothing is written when iterations == 0
  * (the reference's loop does not run).  spec_out may be NULL (= gomel_istft).  Runs the generic kernels (any batch size). */
 int gomel_istft_spec(gomel_handle* h, const double* magnitudes, size_t n_frames, int32_t iterations, const double* x0, uint64_t seed,

@@ -468,9 +468,6 @@ def test_any_frame_length_from_mel_to_mel_istft(oracle, N, hop, K, fmax):
         gotm = m.ToMel(sig)
         assert gotm.shape == wantm.shape and np.max(np.abs(gotm - wantm)) < 1e-8
 
-    if N & 1:
-        return                                                                 # the exported ISTFT takes even lengths only (two self-owned top bins)
-
     class STFT:
         pass
     s = STFT()

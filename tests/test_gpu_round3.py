@@ -191,3 +191,35 @@ def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
     gens, tmg = run(I, k, 1)                                    # generic kernels: no schedule, fp64 throughout
     assert tmg["iter64_launches"] == 0 and tmg["fast_path"] == 0 and all(np.array_equal(a, b) for a, b in zip(gen64, gens))
     assert max(rms(a - b) for a, b in zip(gen64, all64)) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: one rank's shard
+def test_config5_one_rank_shard_of_the_8192_corpus(oracle, coracle):
+    """BASELINE configs[4] shards an 8192-utterance corpus over 8 GPUs: 1024 utterances x 400 frames per rank.  This is
+    rank 3's shard (utterances 3072 ... 4095, seeds = global indices) on the one GPU here, through gomel_from_mel_batch in the
+    calls of 256 bench.py makes: lengths, finiteness, call-to-call determinism, independence from the position inside a call
+    (an utterance gives the same bits alone in another call order), and utterances against the oracle."""
+    import gomel_amd
+    fields = dict(T, GriffinLimIterations=60)
+    U, F, K, first = 1024, 400, 192, 3072
+    m = mel_obj(fields)
+    eng = m.engine()
+    cfg = oracle.MelConfig(**fields)
+    L = oracle.out_len(cfg, F * K)
+    mels, seeds = cfg3_inputs(U, F, K, first=first)
+    outs = []
+    for b0 in range(0, U, 256):
+        outs += eng.from_mel_batch(mels[b0:b0 + 256], None, seeds[b0:b0 + 256])
+    assert len(outs) == U and all(o.shape == (L,) and np.isfinite(o).all() for o in outs)
+    again = eng.from_mel_batch(mels[512:768], None, seeds[512:768])
+    assert all(np.array_equal(a, b) for a, b in zip(again, outs[512:768]))                      # call-to-call bitwise
+    pick = [0, 517, 1023]
+    want, _ = coracle.from_mel_batch(cfg, [mels[u] for u in pick], [oracle.x0_splitmix(seeds[u], L) for u in pick], threads=3)
+    errs = [rms(outs[u] - w) for u, w in zip(pick, want)]
+    print("config 5 shard (utterances %d..%d): rms vs oracle %s" % (first, first + U - 1, ["%.2e" % e for e in errs]))
+    assert np.median(errs) < 1e-5 and max(errs) < 1e-3          # fp32 kernels: the statistical bound of DESIGN.md section 2 (no drift, no systematic error)
+    eng.set_precision(64)                                       # ... and the same three in the mode that promises the tolerance on every utterance
+    o64 = eng.from_mel_batch([mels[u] for u in pick], None, [seeds[u] for u in pick])
+    assert max(rms(a - w) for a, w in zip(o64, want)) < 1e-9
+    sig = np.array([rms(o) for o in outs])
+    assert 0.1 < sig.min() and sig.max() < 0.5                                                  # every utterance a signal of the expected level (0.25)

@@ -127,8 +127,9 @@ def go_probe():
 
 
 # ------------------------------------------------------------------------------------------------ the measured legs
-def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier, pinned=True):
-    """The metric: K calls of gomel_from_mel_batch per BLOCK of the rank's shard, host buffers in, host buffers out."""
+def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier, pinned=True, io32=False):
+    """The metric: K calls of gomel_from_mel_batch per BLOCK of the rank's shard, host buffers in, host buffers out.
+    (io32: the float32 host-I/O entry point, gomel_from_mel_batch_f32 -- an informational side figure, never `value`.)"""
     import gomel_amd
     import torch
     K = fields["NumMels"]
@@ -137,7 +138,9 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     # geometry); a larger one re-uses one block of BLOCK utterances' buffers with the shard's own seeds
     whole = n_local <= MATERIALISE
     nmat = n_local if whole else nb
-    alloc = gomel_amd.host_alloc if pinned else (lambda shape, dtype=np.float64: np.zeros(shape, dtype=dtype))
+    dt = np.float32 if io32 else np.float64
+    alloc = (lambda shape: gomel_amd.host_alloc(shape, dtype=dt)) if pinned else (lambda shape: np.zeros(shape, dtype=dt))
+    call = engine.from_mel_batch_f32 if io32 else engine.from_mel_batch
     mels = []
     for u, src in enumerate(make_inputs(fields, nmat, frames, first)):
         a = alloc((frames * K, 2))
@@ -153,7 +156,7 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
         for b0, cnt in blocks:
             seeds = [1000 + first + b0 + u for u in range(cnt)]      # the seed of an utterance is its GLOBAL index
             m0 = b0 if whole else 0
-            engine.from_mel_batch(mels[m0:m0 + cnt], None, seeds, outs[m0:m0 + cnt])
+            call(mels[m0:m0 + cnt], None, seeds, outs[m0:m0 + cnt])
 
     for _ in range(warmup):
         step()
@@ -382,7 +385,7 @@ def main():
     tm_chunk = resident(engine, fields, max(1, round(nb / m_full)), frames, first, 3)[1] if n_chunks > 1 else tm
 
     side = rank == 0 and world == 1 and not args.no_single           # side measurements: N = 1 only
-    single = pageable = cfg1 = None
+    single = pageable = cfg1 = f32io = None
     if side:
         if wl != "cfg2":
             d2, f2, u2, fr2, sr2 = WORKLOADS["cfg2"]
@@ -395,6 +398,8 @@ def main():
             e2.close()
         el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
         pageable = min(n_utt, BLOCK) * frames * 3 / el_p
+        el_f, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, io32=True)
+        f32io = min(n_utt, BLOCK) * frames * 3 / el_f
         cfg1 = config1(local_rank)
     # The PARITY modes on the same clock (N = 1): the very batch of the fp32 leg through 64-bit mode (fp64 kernels throughout: the
     # mode that agrees with the reference's float64 arithmetic on every input) and through the precision schedule (the first
@@ -460,6 +465,7 @@ def main():
             "real_time_factor": value * hop / sr,
             "resident_frames_per_s": res_fps,
             "pageable_frames_per_s": pageable,
+            "float32_host_io_frames_per_s": f32io,   # gomel_from_mel_batch_f32: float log-mel in, float waveforms out (half the PCIe bytes); informational
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
                          "launch_ms_per_timed_call": tm.get("per_call_launch_ms"),

@@ -1464,6 +1464,174 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
         }
     }
 }
+// The any-hop form of the fp64 fused kernel: k_gl_fused_any's scheme (window and overlap-add accumulator shifted through the stream's
+// LDS area by hop samples per frame, tails folded into x behind every launch) on k_gl_fused_d's types, so that 64-bit mode keeps a
+// fused kernel at hops that are no multiple of N/16 (441, 882, 275 ...) instead of falling to the generic fp64 pair.  ODD shifts by
+// doubles (16-byte LDS reads at 8-byte alignment).  NR: rows that may take new samples, 8 (hops up to N/2) or 16.
+template <int N, int NR, bool ODD>
+__global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const double* __restrict__ x_in, double* __restrict__ x_out, double* __restrict__ tail_out,
+                                                                    const SegDesc* __restrict__ segs, int n_segs, int g_max,
+                                                                    const double* __restrict__ mag, const double* __restrict__ nyq, int hop, DevTables tb) {
+    typedef Geo<N> G;
+    constexpr int T = G::T, STREAMS = kFusedThreads / T, P = N / 2;
+    static_assert(G::LDS_SLOTS > P, "the stream's exchange area must take one window of pairs (and the double behind it)");
+    typedef v2d v2d_a8 __attribute__((aligned(8)));
+    extern __shared__ __attribute__((aligned(16))) char fused_d_smem[];
+    v2d* lds = reinterpret_cast<v2d*>(fused_d_smem);      // [STREAMS * LDS_SLOTS | TW1 | TW2 | window pairs | STREAMS ints]
+    v2d* tw1_l = lds + STREAMS * G::LDS_SLOTS;
+    v2d* tw2_l = tw1_l + G::TW1_N;
+    v2d* win_l = tw2_l + G::TW2_N;
+    int* g_sh = reinterpret_cast<int*>(win_l + G::C);
+    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
+    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
+    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
+    __syncthreads();
+    const Twiddles<v2d> tw{tw1_l, tw2_l, nullptr};
+    auto sync = [] {
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    int seg = blockIdx.x * STREAMS + stream;
+    const bool live = seg < n_segs;
+    if (!live) seg = n_segs - 1;
+    SegDesc d = segs[seg];
+    v2d* my = lds + stream * G::LDS_SLOTS;
+    if constexpr (T >= 64) {
+        d.G = __builtin_amdgcn_readfirstlane(d.G);
+        d.has_next = __builtin_amdgcn_readfirstlane(d.has_next);
+        seg = __builtin_amdgcn_readfirstlane(seg);
+    }
+    constexpr bool WU = (T >= 64);
+    auto uo = [](long long v) { if constexpr (WU) return uniform_i64(v); else return v; };
+    const int h2 = hop / 2, keep2 = P - h2;                                   // pairs a frame moves on by / shares with its successor
+    const v2d* xin_p = reinterpret_cast<const v2d*>(x_in) + uo(d.s0 / 2);     // pair i of frame g: xin_p[g h2 + i]
+    v2d* xout_p = reinterpret_cast<v2d*>(x_out) + uo(d.s0 / 2);
+    v2d* tout = reinterpret_cast<v2d*>(tail_out) + uo((int64_t)seg * keep2);
+    const int keepf = N - hop;                                                // the same in doubles (ODD)
+    const double* xin_f = x_in + uo(d.s0);
+    double* xout_f = x_out + uo(d.s0);
+    double* tout_f = tail_out + uo((int64_t)seg * keepf);
+    const double* myf = reinterpret_cast<const double*>(lds + stream * G::LDS_SLOTS);
+    const double* mag_p = mag + uo(d.frame0 * G::C);
+    const double* nyq_p = nyq + uo(d.frame0);
+    const int owned2 = d.G * h2;
+    if constexpr (STREAMS > 1) {
+        if (t == 0) g_sh[stream] = live ? d.G : 0;
+        __syncthreads();
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < STREAMS; i++) m = max(m, g_sh[i]);
+        g_max = m;
+    } else {
+        g_max = d.G;
+    }
+    v2d xin[16], acc[16], wn[8];
+    const v2d* wl = win_l + t;
+    load_wn<G>(wn, t, tb.wnd);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {   // the first frame's window (x is complete: the tails of the previous iteration have been folded in)
+        if constexpr (ODD) xin[j] = *reinterpret_cast<const v2d_a8*>(xin_f + 2 * (t + T * j));
+        else xin[j] = xin_p[t + T * j];
+        acc[j] = v2d{0.0, 0.0};
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(xin[j]));   // arrived before the loop (k_gl_fused_any: the vmcnt countdown at the loop top)
+    for (int g = 0; g < g_max; g++) {
+        const bool active = live && g < d.G;
+        const int gg = g < d.G ? g : d.G - 1;
+        MagRawD mraw;
+        load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
+        mraw.nq = nyq_p[gg];
+        v2d v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = wl[T * j] * xin[j];
+        // slide the input window by hop samples: through LDS for what stays, from memory for the new samples (in flight during the FFTs)
+        const bool more = g + 1 < d.G;
+        const int base2 = (g + 1) * h2;
+#pragma unroll
+        for (int j = 0; j < 16; j++) my[t + T * j] = xin[j];
+        sync();
+        const unsigned nb2 = (unsigned)(more ? base2 : 0);
+        const unsigned nbf = (unsigned)(more ? (g + 1) * hop : 0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int i = t + T * j;
+            if constexpr (ODD) {
+                const int f0 = 2 * i + hop;                               // the doubles that move down to this slot: f0, f0 + 1, if inside the window
+                const v2d a = *reinterpret_cast<const v2d_a8*>(myf + (f0 < N ? f0 : 0));
+                if (j >= 16 - NR) {
+                    const v2d gl = *reinterpret_cast<const v2d_a8*>(xin_f + nbf + 2u * (unsigned)i);
+                    xin[j] = v2d{f0 < N ? a.x : gl.x, f0 + 1 < N ? a.y : gl.y};
+                } else xin[j] = a;
+            } else {
+                const v2d a = my[i < keep2 ? i + h2 : 0];
+                if (j >= 16 - NR) {
+                    const v2d gl = xin_p[nb2 + (unsigned)i];
+                    xin[j] = i < keep2 ? a : gl;
+                } else xin[j] = a;
+            }
+        }
+        sync();   // the exchange area goes to the FFT now
+        fft_forward<G>(v, my, t, tw, sync);
+        {
+            MagRegsD mr;
+            finish_mags_d(mr, mraw, t == 0);
+            spectral_apply<G>(v, t, mr, wn);
+        }
+        fft_inverse<G>(v, my, t, tw, sync);
+#pragma unroll
+        for (int j = 0; j < 16; j++) asm volatile("" : "+v"(xin[j]));   // the new samples are taken in BEFORE this frame's stores are issued
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] += v[j] * wl[T * j];
+        if (active) {
+            v2d* xo = xout_p + g * h2;
+            double* xof = xout_f + g * hop;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {                                 // rows 0 .. NR-1 hold every finished sample (host: NR covers them)
+                const int i = t + T * j;
+                if constexpr (ODD) {
+                    if (2 * i + 1 < hop) *reinterpret_cast<v2d_a8*>(xof + 2 * i) = acc[j];
+                    else if (2 * i < hop) xof[2 * i] = acc[j].x;            // the odd hop's last sample
+                } else {
+                    if (i < h2) xo[i] = acc[j];
+                }
+            }
+        }
+        sync();   // the inverse FFT's last reads of the exchange area are done
+#pragma unroll
+        for (int j = 0; j < 16; j++) my[t + T * j] = acc[j];
+        sync();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int i = t + T * j;
+            if constexpr (ODD) {
+                const int f0 = 2 * i + hop;
+                const v2d a = *reinterpret_cast<const v2d_a8*>(myf + (f0 < N ? f0 : 0));
+                acc[j] = v2d{f0 < N ? a.x : 0.0, f0 + 1 < N ? a.y : 0.0};
+            } else {
+                const v2d a = my[i < keep2 ? i + h2 : 0];
+                acc[j] = i < keep2 ? a : v2d{0.0, 0.0};
+            }
+        }
+        sync();   // ... before the next frame's window goes through the same area
+        if (active && g == d.G - 1) {
+            v2d* dst = d.has_next ? tout : xout_p + owned2;
+            double* dstf = d.has_next ? tout_f : xout_f + d.G * hop;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = t + T * j;
+                if constexpr (ODD) {
+                    if (2 * i + 1 < keepf) *reinterpret_cast<v2d_a8*>(dstf + 2 * i) = acc[j];
+                    else if (2 * i < keepf) dstf[2 * i] = acc[j].x;
+                } else {
+                    if (i < keep2) dst[i] = acc[j];
+                }
+            }
+        }
+    }
+}
 template <int N> static constexpr size_t fused_d_lds_bytes() {
     typedef Geo<N> G;
     return ((size_t)(kFusedThreads / G::T) * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C) * 16 + (size_t)(kFusedThreads / G::T) * 4 + 16;

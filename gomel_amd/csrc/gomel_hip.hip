@@ -691,9 +691,33 @@ template <int N> static hipError_t launch_fused_d_n(gomel_batch* b, int cur, int
         default: return launch_fused_d_t<N, 8>(b, cur);
     }
 }
+// the any-hop form in fp64 (k_gl_fused_any_d) + the fold of the tails into x, in place (as launch_fused_any)
+template <int N> static hipError_t launch_fused_any_d(gomel_batch* b, int cur) {
+    typedef Geo<N> G;
+    constexpr int STREAMS = kFusedThreads / G::T;
+    constexpr size_t lds = fused_d_lds_bytes<N>();
+    const int n = (int)b->segs.size();
+    const int hop = b->h->cfg.window;
+    const int rows_new = std::max(16 - ((N - hop) / 2) / G::T, ((hop - 1) / 2) / G::T + 1);
+    hipError_t e = hipSuccess;
+#define GOMEL_ANY_D_LAUNCH(NR, ODD)                                                                                                                                  \
+    do {                                                                                                                                                             \
+        if (lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gl_fused_any_d<N, NR, ODD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess)                                                                                                                                          \
+            hipLaunchKernelGGL((k_gl_fused_any_d<N, NR, ODD>), dim3((unsigned)((n + STREAMS - 1) / STREAMS)), dim3(kFusedThreads), lds, run_stream(b), b->d_xd[cur],  \
+                               b->d_xd[cur ^ 1], b->d_taild[0], b->d_segs, n, b->g_max, b->d_magd, b->d_nyqd, hop, b->h->dt);                                        \
+    } while (0)
+    if (hop & 1) { if (rows_new <= 8) GOMEL_ANY_D_LAUNCH(8, true); else GOMEL_ANY_D_LAUNCH(16, true); }
+    else { if (rows_new <= 8) GOMEL_ANY_D_LAUNCH(8, false); else GOMEL_ANY_D_LAUNCH(16, false); }
+#undef GOMEL_ANY_D_LAUNCH
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)n), dim3(256), 0, run_stream(b), b->d_segs, b->d_taild[0], b->d_xd[cur ^ 1], N - hop, hop);
+    return hipSuccess;
+}
 static hipError_t launch_fused_d(gomel_batch* b, int cur) {
     const int N = b->h->cfg.resolut, sh = fused_shift(b->h->cfg);
     hipError_t e = hipSuccess;
+    if (b->fast == 2) { GOMEL_DISPATCH_N(N, e = launch_fused_any_d<NN>(b, cur)); return e; }
     GOMEL_DISPATCH_N(N, e = launch_fused_d_n<NN>(b, cur, sh));
     return e;
 }
@@ -821,7 +845,8 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                     if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
                     curd ^= 1;
                 }
-                hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], b->d_xd[curd], N - c.window, c.window);
+                if (b->fast == 1)   // (the any-hop form folds its tails into x behind every launch)
+                    hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], b->d_xd[curd], N - c.window, c.window);
                 const unsigned gn = (unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536);
                 hipLaunchKernelGGL(k_narrow, dim3(gn), dim3(256), 0, s, b->d_xd[curd], b->d_x[0], b->total_len);
                 HIPCHK(hipMemsetAsync(b->d_tail[0], 0, b->segs.size() * (size_t)(N - c.window) * 4, s));
@@ -835,7 +860,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
                 const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
                 hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
-                hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
+                if (b->fast == 1) hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
             } else {
             if (persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
                 const size_t buf_doubles = (size_t)b->total_frames * N;
@@ -866,7 +891,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             else if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
             if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
-            if (b->fast) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);
+            if (b->fast == 1) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);   // (the any-hop form folds its tails itself)
             }   // !mixed_k
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
@@ -1219,13 +1244,13 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             b->err_slot = h->err_free.back(); h->err_free.pop_back();
         }
     }
-    const int kind = b->precise && fused_kind(c) == 2 ? 0 : fused_kind(c);   // (0 for generic lengths; the any-hop kernel has no fp64 build)
+    const int kind = fused_kind(c);   // (0 for generic lengths)
     b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && kind &&
                (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? kind : 0;
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     // Precision schedule: only where it pays -- the fused kernel's batches.  Everything smaller (persistent / generic kernels: a
     // handful of utterances) and the generic lengths stay fp64 for the whole call: correct, and cheap at that size.
-    if (b->precise && !h->generic && b->fast == 1 && h->precise_iters > 0 && h->precise_iters < I) b->mixed_k = h->precise_iters;
+    if (b->precise && !h->generic && b->fast && h->precise_iters > 0 && h->precise_iters < I) b->mixed_k = h->precise_iters;
     int rc = GOMEL_OK;
     const hipStream_t ist = init_stream ? init_stream : h->stream;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };

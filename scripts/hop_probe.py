@@ -9,6 +9,8 @@ def run(N, hop, K, U=256, F=400, I=20):
     m = gomel_amd.NewMel()
     for k, v in dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=I).items(): setattr(m, k, v)
     e = m.engine()
+    if os.environ.get("GOMEL_PRECISION"):
+        e.set_precision(int(os.environ["GOMEL_PRECISION"]))        # 64: the fp64 kernels (k_gl_fused_d / k_gl_fused_any_d / generic fp64)
     if PATH:
         try:
             e.set_path(PATH)

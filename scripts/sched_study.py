@@ -1,7 +1,7 @@
 """Precision schedule study: K iterations in fp64, the remaining 60-K in fp32 (magnitudes, window, signal rounded to fp32 at the
 switch), against the all-fp64 trajectory.  NumPy emulation; prints per-K error statistics over the utterances given."""
 import os, sys, math, time
-sys.path.insert(0, "/root/repo/oracle")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np, scipy.fft as sf
 import gomel_oracle as go
 from multiprocessing import Pool

@@ -149,7 +149,9 @@ def test_towav_command_line(tmp_path, capsys):
 
 
 # ------------------------------------------------------------------------------------------------ precision schedule
-@pytest.mark.parametrize("fields,frames", [(S, [60, 33, 47, 64, 12, 90]), (T, [40, 25, 64]), (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), [50, 70])])
+@pytest.mark.parametrize("fields,frames", [(S, [60, 33, 47, 64, 12, 90]), (T, [40, 25, 64]), (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), [50, 70]),
+                                           (dict(NumMels=80, MelFmax=8000.0, Window=300, Resolut=1024), [60, 33, 47]),      # any-hop kernels, even hop
+                                           (dict(NumMels=80, MelFmax=8000.0, Window=275, Resolut=2048), [50, 70])])         # ... odd hop
 def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
     """gomel_set_precision_schedule(h, k): the first k iterations in fp64 (k_gl_fused_d), the signal handed over once (tails folded
     in, rounded to fp32), the remaining iterations in fp32 (k_gl_fused).  That is exactly: a 64-bit call of k iterations, then an
@@ -174,7 +176,7 @@ def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
         return out, tm
 
     mixed, tm = run(I, k, 2)
-    assert tm["iter_launches"] == I and tm["iter64_launches"] == k and tm["fast_path"] == 1, tm
+    assert tm["iter_launches"] == I and tm["iter64_launches"] == k and tm["fast_path"] in (1, 3), tm
     first, tm1 = run(k, -1, 2)                                  # k iterations, fp64 throughout
     assert tm1["iter64_launches"] == k
     second, tm2 = run(I - k, 0, 2, x0s=first)                   # I - k iterations, fp32 throughout, from there
@@ -223,3 +225,36 @@ def test_config5_one_rank_shard_of_the_8192_corpus(oracle, coracle):
     assert max(rms(a - w) for a, w in zip(o64, want)) < 1e-9
     sig = np.array([rms(o) for o in outs])
     assert 0.1 < sig.min() and sig.max() < 0.5                                                  # every utterance a signal of the expected level (0.25)
+
+
+# ------------------------------------------------------------------------------------------------ 64-bit mode at hops that are no multiple of N/16
+@pytest.mark.parametrize("N,hop,K", [(4096, 882, 96), (4096, 441, 96), (4096, 2050, 96), (4096, 3001, 96), (2048, 276, 80), (2048, 275, 80), (2048, 1025, 80),
+                                      (1024, 300, 80), (1024, 275, 80), (1024, 600, 80), (512, 100, 40), (512, 161, 40), (256, 50, 40), (256, 51, 40), (256, 255, 40)])
+def test_any_hop_fused_kernel_in_64_bit_mode(oracle, N, hop, K):
+    """k_gl_fused_any_d: 64-bit mode keeps a fused kernel at hops that are no multiple of N/16 (even hops: the window moves through LDS
+    by pairs, odd hops: by doubles).  Against the generic fp64 kernels (same arithmetic per frame, other summation order of the
+    overlap-add) on a ragged batch, and against the fp64 oracle at the level 64-bit mode promises."""
+    import gomel_amd
+    fields = dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=4)
+    gmin = (N - 1) // hop
+    frames = [gmin * 4 + 3, 1, 2, gmin + 1, 150, 64, 65]
+    mels = [oracle.random_logmel(f, K, seed=500 + i) for i, f in enumerate(frames)]
+    seeds = list(range(len(frames)))
+    outs = {}
+    for path in (2, 1):
+        m = mel_obj(fields)
+        e = m.engine()
+        e.set_path(path)
+        e.set_precision(64)
+        b = gomel_amd.Batch(e, [len(mm) for mm in mels])
+        b.upload(mels, None, seeds)
+        tm = b.run_timed()
+        assert tm["fast_path"] == (3 if path == 2 else 0) and tm["iter64_launches"] == (4 if path == 2 else 0), tm
+        outs[path] = b.download()
+        b.close(); e.close()
+    for a, r in zip(outs[2], outs[1]):
+        assert a.shape == r.shape and rms(a - r) < 1e-12 * max(1.0, rms(r)), rms(a - r)
+    cfg = oracle.MelConfig(**fields)
+    for i in (0, 1, 4):
+        want = oracle.from_mel(cfg, mels[i].copy(), oracle.x0_splitmix(seeds[i], len(outs[2][i])))
+        assert rms(outs[2][i] - want) < 1e-9 * max(1.0, rms(want))

@@ -410,6 +410,36 @@ struct SegDesc {
 };
 
 constexpr int kFusedThreads = 256;
+// The workgroup's tables (pass-1 / pass-2 twiddles, window) from global memory into LDS: 16 bytes per lane and instruction, EVERY load
+// issued before the first LDS write, so the fill costs one memory round trip (the element-wise loops it replaces went out in batches
+// of five 8-byte loads, each batch waited for).  A chunk-sized launch of a host-to-host call pays this once per 12.5 frames: -1 % on
+// those launches at N 4096 (profiles/r03/ab_wide_fill.txt), nothing on whole-batch launches; the small tables of N <= 1024 keep the
+// loops (the wide form measured +2.5 % there).
+template <bool ALIGNED16, int N1, int N2, int N3>
+GL_DEV void fill_tables_lds(v2f* d1, v2f* d2, v2f* d3, const v2f* __restrict__ s1, const v2f* __restrict__ s2, const v2f* __restrict__ s3) {
+    if constexpr (ALIGNED16 && N1 % 2 == 0 && N2 % 2 == 0 && N3 % 2 == 0) {
+        constexpr int Q1 = N1 / 2, Q2 = N2 / 2, Q3 = N3 / 2;
+        constexpr int K1 = (Q1 + kFusedThreads - 1) / kFusedThreads, K2 = (Q2 + kFusedThreads - 1) / kFusedThreads, K3 = (Q3 + kFusedThreads - 1) / kFusedThreads;
+        v4f a1[K1], a2[K2], a3[K3];
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < K1; k++) a1[k] = reinterpret_cast<const v4f*>(s1)[min(t + kFusedThreads * k, Q1 - 1)];
+#pragma unroll
+        for (int k = 0; k < K2; k++) a2[k] = reinterpret_cast<const v4f*>(s2)[min(t + kFusedThreads * k, Q2 - 1)];
+#pragma unroll
+        for (int k = 0; k < K3; k++) a3[k] = reinterpret_cast<const v4f*>(s3)[min(t + kFusedThreads * k, Q3 - 1)];
+#pragma unroll
+        for (int k = 0; k < K1; k++) if (t + kFusedThreads * k < Q1) reinterpret_cast<v4f*>(d1)[t + kFusedThreads * k] = a1[k];
+#pragma unroll
+        for (int k = 0; k < K2; k++) if (t + kFusedThreads * k < Q2) reinterpret_cast<v4f*>(d2)[t + kFusedThreads * k] = a2[k];
+#pragma unroll
+        for (int k = 0; k < K3; k++) if (t + kFusedThreads * k < Q3) reinterpret_cast<v4f*>(d3)[t + kFusedThreads * k] = a3[k];
+    } else {
+        for (int i = threadIdx.x; i < N1; i += kFusedThreads) d1[i] = s1[i];
+        for (int i = threadIdx.x; i < N2; i += kFusedThreads) d2[i] = s2[i];
+        for (int i = threadIdx.x; i < N3; i += kFusedThreads) d3[i] = s3[i];
+    }
+}
 // Per-geometry register budget of k_gl_fused (254-256 VGPRs everywhere): how many pass-1 twiddles stay in registers, and whether
 // the next frame's rows are requested before the forward FFT (N 4096: the inverse FFT alone does not cover their HBM latency) or
 // after the spectral step (shorter live range: room for the twiddles).  Chosen so that no instantiation spills (hipcc -S audit).
@@ -834,13 +864,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = kFusedThreads / T, KEEP = 16 - SH, TAIL_PAIRS = KEEP * T;  // tail = (N - hop)/2 pairs
     // LDS: per-stream exchange areas, then the tables every stream of the WG shares (TW1, TW2, window as pairs)
-    __shared__ v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
+    __shared__ __attribute__((aligned(16))) v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
     v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
     v2f* tw2_l = tw1_l + G::TW1_N;
     v2f* win_l = tw2_l + G::TW2_N;
-    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1[i];
-    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2[i];
-    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
+    fill_tables_lds<(STREAMS * G::LDS_SLOTS) % 2 == 0 && N >= 2048, G::TW1_N, G::TW2_N, G::C>(tw1_l, tw2_l, win_l, tb.tw1, tb.tw2, reinterpret_cast<const v2f*>(tb.window));
     __syncthreads();
     // this lane's pass-2 twiddles depend on the lane only: registers for the whole segment instead of 30 LDS reads per frame
     // (measured -3 % at N 4096, -2 % at N 1024: the kernel is power-limited and LDS table bytes are part of the bill; 254 VGPRs)
@@ -1113,13 +1141,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
     constexpr int T = G::T, STREAMS = kFusedThreads / T, P = N / 2;
     static_assert(G::LDS_SLOTS > P, "the stream's exchange area must take one window of pairs (and the float behind it)");
     typedef v2f v2f_a4 __attribute__((aligned(4)));
-    __shared__ v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
+    __shared__ __attribute__((aligned(16))) v2f lds[STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C];
     v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
     v2f* tw2_l = tw1_l + G::TW1_N;
     v2f* win_l = tw2_l + G::TW2_N;
-    for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1[i];
-    for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2[i];
-    for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2f*>(tb.window)[i];
+    fill_tables_lds<(STREAMS * G::LDS_SLOTS) % 2 == 0 && N >= 2048, G::TW1_N, G::TW2_N, G::C>(tw1_l, tw2_l, win_l, tb.tw1, tb.tw2, reinterpret_cast<const v2f*>(tb.window));
     __syncthreads();
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
     // pass-2 twiddles in registers where the build has room for them (the 4-row builds at even hops: -3 % as in k_gl_fused); the

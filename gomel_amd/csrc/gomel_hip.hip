@@ -1961,6 +1961,17 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
     return rc;
 }
 
+// Diagnostic (not in the header; the tests reach it by name): the persistent path's pause state of a handle, and a way to change the
+// spin limit of a LIVE handle (GOMEL_PERSIST_TICKS is read at creation) so that a test can force a timeout and then let launches
+// complete again.  set_ticks < 0 leaves the limit alone.
+int gomel_debug_persist_state(gomel_handle* h, long long set_ticks, unsigned* backoff, unsigned long long* paused_for) {
+    if (!h) return GOMEL_ERR_NULL;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (set_ticks >= 0) h->persist_ticks = (unsigned)set_ticks;
+    if (backoff) *backoff = h->persist_backoff;
+    if (paused_for) *paused_for = h->persist_retry_at > h->batches_seen ? h->persist_retry_at - h->batches_seen : 0;
+    return GOMEL_OK;
+}
 #ifdef GOMEL_STAMPS   // diagnostic build only: read (and clear) the per-phase cycle sums of k_gl_fused
 int gomel_debug_stamps(unsigned long long* out21, int clear) {
     if (out21 && hipMemcpyFromSymbol(out21, HIP_SYMBOL(g_stamp_acc), 21 * sizeof(unsigned long long)) != hipSuccess) return GOMEL_ERR_HIP;

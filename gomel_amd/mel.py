@@ -93,6 +93,16 @@ class Engine:
         """The first `fp64_iterations` iterations of every call in fp64, the rest in fp32 (gomel_set_precision_schedule)."""
         check(_lib.lib().gomel_set_precision_schedule(self._h, int(fp64_iterations)), "gomel_set_precision_schedule")
 
+    def plan_chunks(self, n_pairs):
+        """gomel_plan_chunks: how a gomel_from_mel_batch call over utterances of these lengths is cut -- the utterance indices
+        [0, b1, ..., n] at which its chunks begin and end (host logic, no device work)."""
+        n = len(n_pairs)
+        np_ = (ctypes.c_size_t * max(n, 1))(*[int(v) for v in n_pairs])
+        bounds = (ctypes.c_size_t * (n + 2))()
+        nch = ctypes.c_size_t(0)
+        check(_lib.lib().gomel_plan_chunks(ctypes.byref(self.cfg), n, np_, bounds, n + 2, ctypes.byref(nch)), "gomel_plan_chunks")
+        return [int(bounds[i]) for i in range(nch.value + 1)]
+
     def device_name(self):
         buf = ctypes.create_string_buffer(256)
         check(_lib.lib().gomel_device_name(self._h, buf, 256), "gomel_device_name")

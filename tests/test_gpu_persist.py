@@ -316,3 +316,51 @@ def test_a_timeout_pauses_the_path_and_it_comes_back(oracle, monkeypatch):
         first = paths.index(0)
         assert all(p == 0 for p in paths[first:first + 64])
     e.close()
+
+
+def test_a_completed_launch_ends_the_escalation_of_the_pause(oracle):
+    """The pause after a timeout doubles with every further timeout (64, 128, ... 4096 batches); the first persistent launch that
+    runs through resets it to 64, so that a long-lived handle does not carry the escalation of a few bad moments for ever.
+    (gomel_debug_persist_state: a diagnostic entry point that reads the pause state and changes the spin limit of a live handle.)"""
+    import ctypes
+    import gomel_amd
+    from gomel_amd import _lib
+    L = _lib.lib()
+    L.gomel_debug_persist_state.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_ulonglong)]
+    L.gomel_debug_persist_state.restype = ctypes.c_int
+    N, hop, K, F, I = 1024, 256, 80, 60, 4
+    mel = oracle.random_logmel(F, K, seed=5)
+    mg, eg = engine(N, hop, K, I, GENERIC)
+    (ref,), _ = run(eg, [mel], [2])
+    eg.close()
+    m, e = engine(N, hop, K, I, 0)
+    backoff, paused = ctypes.c_uint(0), ctypes.c_ulonglong(0)
+
+    def state(set_ticks=-1):
+        assert L.gomel_debug_persist_state(e._h, set_ticks, ctypes.byref(backoff), ctypes.byref(paused)) == 0
+        return backoff.value, paused.value
+
+    def one():
+        b = gomel_amd.Batch(e, [F * K])
+        b.upload([mel], None, [2])
+        path = b.run_timed()["fast_path"]
+        assert np.array_equal(b.download()[0], ref)
+        b.close()
+        return path
+
+    assert state() == (64, 0)
+    state(0)                                   # every wait that is not satisfied at its first poll gives up
+    gave_up = False
+    for _ in range(8):                         # (a launch whose every poll hits at once completes even so: try a few times)
+        if one() == 0:
+            gave_up = True
+            break
+    if not gave_up:
+        pytest.skip("no poll ever missed on this box: the timeout could not be provoked")
+    bo, paused_for = state(20 * 100000)        # the default limit again
+    assert bo == 128 and 0 < paused_for <= 64  # paused for 64 batches, the next pause would be 128
+    for _ in range(int(paused_for) - 1):      # (the batch that gave up was the first of the 64)
+        assert one() == 0                      # the pause: per-iteration kernels
+    assert one() == 2                          # the retry runs through ...
+    assert state() == (64, 0)                  # ... and the escalation is over
+    e.close()

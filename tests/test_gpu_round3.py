@@ -258,3 +258,38 @@ def test_any_hop_fused_kernel_in_64_bit_mode(oracle, N, hop, K):
     for i in (0, 1, 4):
         want = oracle.from_mel(cfg, mels[i].copy(), oracle.x0_splitmix(seeds[i], len(outs[2][i])))
         assert rms(outs[2][i] - want) < 1e-9 * max(1.0, rms(want))
+
+
+def test_host_to_host_call_in_the_parity_modes(oracle, coracle):
+    """gomel_from_mel_batch (the chunked upload | compute | download pipeline, what bench.py times) in 64-bit mode and under the
+    precision schedule: 64 utterances x 200 frames is enough for the call to be cut into chunks, each of which the fused kernels
+    take.  64-bit mode agrees with the oracle at rounding level whatever the chunking; the schedule stays far inside the bar; a
+    Batch of the same utterances (one whole-batch plan: other segments, other summation order) gives the same within rounding."""
+    import gomel_amd
+    fields = dict(T, GriffinLimIterations=20)
+    U, F, K = 64, 200, 192
+    mels, seeds = cfg3_inputs(U, F, K, first=7000)
+    m = mel_obj(fields)
+    eng = m.engine()
+    cfg = oracle.MelConfig(**fields)
+    L = oracle.out_len(cfg, F * K)
+    assert eng.plan_chunks([F * K] * U)[-1] == U and len(eng.plan_chunks([F * K] * U)) > 2          # more than one chunk
+    pick = list(range(0, U, 7))
+    want, _ = coracle.from_mel_batch(cfg, [mels[u] for u in pick], [oracle.x0_splitmix(seeds[u], L) for u in pick], threads=min(10, os.cpu_count() or 1))
+    eng.set_precision(64)
+    o64 = eng.from_mel_batch(mels, None, seeds)
+    assert max(rms(o64[u] - w) for u, w in zip(pick, want)) < 1e-9
+    b = gomel_amd.Batch(eng, [F * K] * U)
+    b.upload(mels, None, seeds)
+    b.run()
+    r64 = b.download()
+    b.close()
+    assert max(rms(a - c) for a, c in zip(o64, r64)) < 1e-11
+    eng.set_precision_schedule(10)
+    osch = eng.from_mel_batch(mels, None, seeds)
+    esch = [rms(osch[u] - w) for u, w in zip(pick, want)]
+    print("host-to-host, schedule 10 + 10: max %.2e" % max(esch))
+    assert max(esch) < 1e-5
+    eng.set_precision_schedule(0)
+    o32 = eng.from_mel_batch(mels, None, seeds)
+    assert max(rms(o32[u] - w) for u, w in zip(pick, want)) < RMS_TOL                                # 20 iterations: fp32 is still at 1e-6

@@ -289,7 +289,7 @@ def cpu_legs(fields, frames, mels, seeds, outs_by_mode, mode):
                         "oracle": "oracle/gomel_oracle.c (fp64 restatement, parity unpinned: no Go toolchain / reference vectors)"}
     if "fp32" in parity:
         parity["fp32"]["note"] = ("fp32 kernels vs fp64 reference arithmetic on iid-random (inconsistent) spectrograms: see DESIGN.md 'Parity in numbers'; "
-                                  "the `precise` block holds the modes that meet the tolerance on every utterance")
+                                  "the parity modes (64-bit mode, precision schedule) meet the tolerance on every utterance: `precise` block of the N = 1 line")
     return cpu, parity
 
 

@@ -295,6 +295,21 @@ struct Stamps {
     }
 };
 
+// ---------------------------------------------------------------------------------------------- exchange synchronisation
+// The passes below synchronise a stream's lanes at two kinds of points: behind a WRITE burst (the partner's data must be there before
+// anything is read: a full barrier, `sync()`), and behind a READ burst (the partner must have read before the area is written again).
+// The second kind only has to hold by the NEXT WRITE, a whole butterfly later.  A plain callable (`s_barrier`, or nothing for a
+// one-wave stream) takes both as `sync()`.  A split-phase object -- `arrive()` / `wait()`, e.g. per-wave event counters in LDS -- signals
+// "my reads are issued" at once (`sync_reads_done`) and waits for the partner only in front of the next write burst
+// (`sync_before_write`), by which time the partner has long arrived: that wait never stalls.
+template <class S> struct IsSplitSync {
+    template <class U> static auto test(U* u) -> decltype(u->arrive(), char());
+    template <class U> static long test(...);
+    static constexpr bool value = sizeof(test<S>(nullptr)) == sizeof(char);
+};
+template <class S> GL_DEV void sync_reads_done(S& s) { if constexpr (IsSplitSync<S>::value) s.arrive(); else s(); }
+template <class S> GL_DEV void sync_before_write(S& s) { if constexpr (IsSplitSync<S>::value) s.wait(); }
+
 // ---------------------------------------------------------------------------------------------- forward
 // In: v[j] = z[t + T*j].  Out: v[0..7] = Z[bA + B3*r], v[8..15] = Z[bB + B3*r] with bA = t, bB = (t ? B3 - t : B3/2).
 // `lds` is this stream's exchange area (G::LDS_SLOTS slots).  SYNC() is a barrier covering the stream's lanes.
@@ -313,6 +328,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) apply_tw<false, G::NB1, G::R1>(&v[u], &w1[u]);
     st.mark(0);
+    sync_before_write(sync);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
@@ -328,7 +344,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 #pragma unroll
         for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * G::SA + t2 + 8 * m];
     }
-    sync();
+    sync_reads_done(sync);
     st.mark(2);
     V w2[16];
 #pragma unroll
@@ -343,6 +359,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
     st.mark(3);
+    sync_before_write(sync);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
@@ -355,7 +372,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
 #pragma unroll
     for (int r = 0; r < 8; r++) { v[r] = lds[r * G::SB + bA]; v[8 + r] = lds[r * G::SB + bB]; }
-    sync();
+    sync_reads_done(sync);
     st.mark(5);
     dft8<false, 1>(&v[0]);
     dft8<false, 1>(&v[8]);
@@ -365,11 +382,14 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 // ---------------------------------------------------------------------------------------------- inverse
 // In: v[0..7] = Z'[bA + B3*r], v[8..15] = Z'[bB + B3*r].  Out: v[j] = sum_k Z'[k] e^{+2 pi i nk/C}, n = t + T*j
 // (unnormalised; the 1/N of fft.IFFT is folded into the target magnitudes).
-template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
+// `w1_out` (optional): receives this lane's pass-1 twiddles as they are read (index u + NB1*q, the layout of Twiddles::w1r), so that a
+// kernel whose next step is a forward FFT can hand them to it instead of reading the table again.
+template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st, V* w1_out = nullptr) {
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
     dft8<true, 1>(&v[0]);
     dft8<true, 1>(&v[8]);
     st.mark(8);
+    sync_before_write(sync);
 #pragma unroll
     for (int r = 0; r < 8; r++) { lds[r * G::SB + bA] = v[r]; lds[r * G::SB + bB] = v[8 + r]; }
     sync();
@@ -385,12 +405,13 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v
         }
         apply_tw<true, 1, G::R2>(&v[u * G::R2], w2);
     }
-    sync();
+    sync_reads_done(sync);
     st.mark(10);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
         dftR<true, G::R2, 1>(&v[u * G::R2]);
+        if (u == 0) sync_before_write(sync);
 #pragma unroll
         for (int m = 0; m < G::R2; m++) lds[q1 * G::SAI + t2 + 8 * m] = v[u * G::R2 + m];
     }
@@ -404,10 +425,11 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v
         for (int q = 0; q < G::R1; q++) {
             v[u + G::NB1 * q] = lds[q * G::SAI + t1];
             if (q) w1[G::NB1 * q] = (tw.w1r && q <= tw.w1r_n) ? tw.w1r[u + G::NB1 * q] : tw.tw1[q * G::C1 + t1];
+            if (q && w1_out) w1_out[u + G::NB1 * q] = w1[G::NB1 * q];
         }
         apply_tw<true, G::NB1, G::R1>(&v[u], w1);
     }
-    sync();
+    sync_reads_done(sync);
     st.mark(12);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<true, G::R1, G::NB1>(&v[u]);

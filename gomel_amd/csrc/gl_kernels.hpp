@@ -409,6 +409,32 @@ struct SegDesc {
     int32_t pad_;
 };
 
+// Split-phase synchronisation of a two-wave stream through LDS (gl_fft.hpp, "exchange synchronisation"): every wave counts its own
+// events -- write burst done, read burst issued -- in a word of its own; `arrive()` publishes the count (one ds_write_b32, queued behind
+// the wave's data accesses: the LDS executes a wave's instructions in order), `wait()` polls the partner's word until it shows the same
+// count.  Both waves run the same event sequence, so "the partner has reached my latest event" is the one condition ever needed.
+// WIDE = false (streams within one wave): program order is the synchronisation, as everywhere else.
+template <bool WIDE> struct StreamFlagSync {
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    unsigned* mine; unsigned* other; unsigned& ev;
+    GL_DEV void arrive() {
+        if constexpr (WIDE) {
+            ev++;
+            asm volatile("" ::: "memory");
+            *(volatile lds_u32*)mine = ev;      // every lane writes the same value: one ds_write_b32
+            asm volatile("" ::: "memory");
+        } else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    }
+    GL_DEV void wait() {
+        if constexpr (WIDE) {
+            asm volatile("" ::: "memory");
+            while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {}
+            asm volatile("" ::: "memory");
+        }
+    }
+    GL_DEV void operator()() { arrive(); wait(); }
+};
+
 constexpr int kFusedThreads = 256;
 // The workgroup's tables (pass-1 / pass-2 twiddles, window) from global memory into LDS: 16 bytes per lane and instruction, EVERY load
 // issued before the first LDS write, so the fill costs one memory round trip (the element-wise loops it replaces went out in batches
@@ -889,12 +915,15 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         // Exchange synchronisation.  A stream of T <= 64 lanes lives inside ONE wave, whose LDS operations execute in program
     // order: its exchanges need no s_barrier, only a compiler-level fence so that loads/stores are not reordered.  Wider
     // streams (N = 4096: two waves) use the workgroup barrier.
+    const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    // (StreamFlagSync -- the fp64 kernel's per-stream synchronisation through LDS event counters -- was measured here too: bit-identical,
+    // 0.587 -> 0.589 ms; with two waves per SIMD the other workgroup already fills what a barrier leaves idle.  s_barrier stays.)
     auto sync = [] {
         if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     };
+    constexpr bool COUPLED = STREAMS > 1;
 
-    const int stream = threadIdx.x / T, t = threadIdx.x % T;
     int seg = blockIdx.x * STREAMS + stream;
     const bool live = seg < n_segs;
     if (!live) seg = n_segs - 1;
@@ -921,7 +950,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     const float* nyq_p = nyq + uo(d.frame0);
     const float f_prev = d.has_prev ? 1.f : 0.f, f_next = d.has_next ? 1.f : 0.f;
     const int rows_owned = d.G * SH;  // rows >= this belong to the next segment's head
-    if constexpr (STREAMS > 1) {  // streams of one WG share the barriers: loop to the longest segment among them
+    if constexpr (COUPLED) {  // streams of one WG share the barriers: loop to the longest segment among them
         __shared__ int g_sh[STREAMS];
         if (t == 0) g_sh[stream] = live ? d.G : 0;
         __syncthreads();
@@ -1362,16 +1391,21 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
     int* g_sh = reinterpret_cast<int*>(win_l + G::C);
+    unsigned* cnt_sh = reinterpret_cast<unsigned*>(g_sh + STREAMS);   // [STREAMS][2]: one event counter per wave of a two-wave stream (N 4096)
+    if constexpr (T > 64) { if (threadIdx.x < 2 * STREAMS) cnt_sh[threadIdx.x] = 0u; }
     for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
     for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
     __syncthreads();
     const Twiddles<v2d> tw{tw1_l, tw2_l, nullptr};
-    auto sync = [] {
-        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-        else __syncthreads();
-    };
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    // The two waves of a 4096-point stream synchronise through per-wave event counters in LDS (StreamFlagSync) instead of the workgroup's
+    // s_barrier: the workgroup's two streams no longer run in lockstep -- with one wave per SIMD the four waves used to be released
+    // together by every barrier and to send their 16 x ds_read_b128 bursts into the one LDS pipe at the same moment -- and the
+    // read -> write points become split-phase (the wait sits in front of the next write burst, where it never stalls):
+    // 1.534 -> 1.378 ms per launch at config 3 (profiles/r03/ab_fp64_flagsync.txt).  Streams inside one wave need neither.
+    unsigned ev = 0;
+    StreamFlagSync<(Geo<N>::T > 64)> sync{cnt_sh + 2 * stream + ((threadIdx.x % T) >> 6), cnt_sh + 2 * stream + (((threadIdx.x % T) >> 6) ^ 1), ev};
     int seg = blockIdx.x * STREAMS + stream;
     const bool live = seg < n_segs;
     if (!live) seg = n_segs - 1;
@@ -1395,7 +1429,8 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     const double* nyq_p = nyq + uo(d.frame0);
     const double f_prev = d.has_prev ? 1.0 : 0.0, f_next = d.has_next ? 1.0 : 0.0;
     const int rows_owned = d.G * SH;
-    if constexpr (STREAMS > 1) {
+    constexpr bool COUPLED = STREAMS > 1 && T <= 64;   // (two-wave streams have their own synchronisation: each runs its own length)
+    if constexpr (COUPLED) {
         if (t == 0) g_sh[stream] = live ? d.G : 0;
         __syncthreads();
         int m = 0;
@@ -1418,6 +1453,17 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     }
 #pragma unroll
     for (int j = 0; j < KEEP; j++) acc[j] = v2d{0.0, 0.0};
+    // One pass-1 twiddle read per frame at N 4096: the 15 values the inverse FFT reads at its end serve the next frame's forward FFT,
+    // which starts a few hundred instructions later (15 of a frame's ~156 LDS reads; +1.6 % vector instructions for the registers
+    // that cross the back edge; measured -1.2 % at N 4096, +1.7 % at N 1024 -- there the table is read twice, profiles/r03/ab_fp64_w1carry.txt)
+    constexpr bool W1CARRY = N >= 4096;
+    v2d w1c[16];
+    if constexpr (W1CARRY) {
+#pragma unroll
+        for (int u = 0; u < G::NB1; u++)
+#pragma unroll
+            for (int q = 0; q < G::R1; q++) w1c[u + G::NB1 * q] = tw1_l[q * G::C1 + t + T * u];
+    }
 
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
@@ -1447,13 +1493,18 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
                 fl[jj] = in_next ? 1.0 : 0.0;
             }
         }
-        fft_forward<G>(v, my, t, tw, sync);
+        if constexpr (W1CARRY) {
+            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr};
+            fft_forward<G>(v, my, t, twf, sync);
+        } else {
+            fft_forward<G>(v, my, t, tw, sync);
+        }
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
             spectral_apply<G>(v, t, mr, wn);
         }
-        fft_inverse<G>(v, my, t, tw, sync);
+        { NoStamps nst; fft_inverse<G>(v, my, t, tw, sync, nst, W1CARRY ? w1c : nullptr); }
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] = xl[jj];
         if (any_next) {
@@ -1508,16 +1559,16 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
     int* g_sh = reinterpret_cast<int*>(win_l + G::C);
+    unsigned* cnt_sh = reinterpret_cast<unsigned*>(g_sh + STREAMS);   // event counters of the two-wave streams (k_gl_fused_d)
+    if constexpr (T > 64) { if (threadIdx.x < 2 * STREAMS) cnt_sh[threadIdx.x] = 0u; }
     for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
     for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
     __syncthreads();
     const Twiddles<v2d> tw{tw1_l, tw2_l, nullptr};
-    auto sync = [] {
-        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-        else __syncthreads();
-    };
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
+    unsigned ev = 0;   // two-wave streams: per-stream split-phase synchronisation, as k_gl_fused_d
+    StreamFlagSync<(Geo<N>::T > 64)> sync{cnt_sh + 2 * stream + ((threadIdx.x % T) >> 6), cnt_sh + 2 * stream + (((threadIdx.x % T) >> 6) ^ 1), ev};
     int seg = blockIdx.x * STREAMS + stream;
     const bool live = seg < n_segs;
     if (!live) seg = n_segs - 1;
@@ -1542,7 +1593,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     const double* mag_p = mag + uo(d.frame0 * G::C);
     const double* nyq_p = nyq + uo(d.frame0);
     const int owned2 = d.G * h2;
-    if constexpr (STREAMS > 1) {
+    if constexpr (STREAMS > 1 && T <= 64) {
         if (t == 0) g_sh[stream] = live ? d.G : 0;
         __syncthreads();
         int m = 0;
@@ -1660,7 +1711,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
 }
 template <int N> static constexpr size_t fused_d_lds_bytes() {
     typedef Geo<N> G;
-    return ((size_t)(kFusedThreads / G::T) * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C) * 16 + (size_t)(kFusedThreads / G::T) * 4 + 16;
+    return ((size_t)(kFusedThreads / G::T) * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C) * 16 + (size_t)(kFusedThreads / G::T) * 12 + 16;   // + g_sh[STREAMS] + the event counters [STREAMS][2]
 }
 // out = x + tails, both fp64 (the fp64 fused path's last step)
 __global__ __launch_bounds__(256) void k_add_tails_d(const SegDesc* __restrict__ segs, const double* __restrict__ tail, double* __restrict__ out,

@@ -1559,16 +1559,18 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
     int* g_sh = reinterpret_cast<int*>(win_l + G::C);
-    unsigned* cnt_sh = reinterpret_cast<unsigned*>(g_sh + STREAMS);   // event counters of the two-wave streams (k_gl_fused_d)
-    if constexpr (T > 64) { if (threadIdx.x < 2 * STREAMS) cnt_sh[threadIdx.x] = 0u; }
     for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
     for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
     __syncthreads();
     const Twiddles<v2d> tw{tw1_l, tw2_l, nullptr};
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
-    unsigned ev = 0;   // two-wave streams: per-stream split-phase synchronisation, as k_gl_fused_d
-    StreamFlagSync<(Geo<N>::T > 64)> sync{cnt_sh + 2 * stream + ((threadIdx.x % T) >> 6), cnt_sh + 2 * stream + (((threadIdx.x % T) >> 6) ^ 1), ev};
+    // (k_gl_fused_d's StreamFlagSync was measured here: this kernel has six more exchange points per frame -- the two shift passes --
+    // each a full arrive + wait at ~200 cycles against an s_barrier's few dozen: 1.81 -> 2.41 ms per launch at N 4096 / hop 882.  s_barrier stays.)
+    auto sync = [] {
+        if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
     int seg = blockIdx.x * STREAMS + stream;
     const bool live = seg < n_segs;
     if (!live) seg = n_segs - 1;
@@ -1593,7 +1595,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     const double* mag_p = mag + uo(d.frame0 * G::C);
     const double* nyq_p = nyq + uo(d.frame0);
     const int owned2 = d.G * h2;
-    if constexpr (STREAMS > 1 && T <= 64) {
+    if constexpr (STREAMS > 1) {
         if (t == 0) g_sh[stream] = live ? d.G : 0;
         __syncthreads();
         int m = 0;

@@ -1565,8 +1565,9 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     __syncthreads();
     const Twiddles<v2d> tw{tw1_l, tw2_l, nullptr};
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
-    // (k_gl_fused_d's StreamFlagSync was measured here: this kernel has six more exchange points per frame -- the two shift passes --
-    // each a full arrive + wait at ~200 cycles against an s_barrier's few dozen: 1.81 -> 2.41 ms per launch at N 4096 / hop 882.  s_barrier stays.)
+    // (k_gl_fused_d's StreamFlagSync was measured here, plain and split-phase: 1.81 -> 2.41 ms per launch at N 4096 / hop 882 either way --
+    // this kernel has six more exchange points per frame for its two shift passes, and spills.  s_barrier stays; the sync_* helpers below
+    // are then plain barriers where the kernel had them before.)
     auto sync = [] {
         if constexpr (Geo<N>::T <= 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -1628,6 +1629,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
         // slide the input window by hop samples: through LDS for what stays, from memory for the new samples (in flight during the FFTs)
         const bool more = g + 1 < d.G;
         const int base2 = (g + 1) * h2;
+        sync_before_write(sync);
 #pragma unroll
         for (int j = 0; j < 16; j++) my[t + T * j] = xin[j];
         sync();
@@ -1651,7 +1653,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
                 } else xin[j] = a;
             }
         }
-        sync();   // the exchange area goes to the FFT now
+        sync_reads_done(sync);   // the exchange area goes to the FFT now (its first write burst waits: sync_before_write)
         fft_forward<G>(v, my, t, tw, sync);
         {
             MagRegsD mr;
@@ -1678,7 +1680,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
                 }
             }
         }
-        sync();   // the inverse FFT's last reads of the exchange area are done
+        sync_area_free(sync);   // the inverse FFT's last reads of the exchange area are done
 #pragma unroll
         for (int j = 0; j < 16; j++) my[t + T * j] = acc[j];
         sync();
@@ -1694,7 +1696,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
                 acc[j] = i < keep2 ? a : v2d{0.0, 0.0};
             }
         }
-        sync();   // ... before the next frame's window goes through the same area
+        sync_reads_done(sync);   // ... before the next frame's window goes through the same area
         if (active && g == d.G - 1) {
             v2d* dst = d.has_next ? tout : xout_p + owned2;
             double* dstf = d.has_next ? tout_f : xout_f + d.G * hop;

@@ -398,9 +398,10 @@ def main():
             e2.close()
         el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
         pageable = min(n_utt, BLOCK) * frames * 3 / el_p
+        cfg1 = config1(local_rank)
+    if rank == 0 and world == 1:                                      # float32 host I/O (half the PCIe bytes): informational, any workload
         el_f, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, io32=True)
         f32io = min(n_utt, BLOCK) * frames * 3 / el_f
-        cfg1 = config1(local_rank)
     # The PARITY modes on the same clock (N = 1): the very batch of the fp32 leg through 64-bit mode (fp64 kernels throughout: the
     # mode that agrees with the reference's float64 arithmetic on every input) and through the precision schedule (the first
     # PARITY_SCHEDULE iterations fp64, the rest fp32) -- host to host like `value`, resident, their kernels' launch times.

@@ -3,7 +3,8 @@
 // The reference takes ANY Resolut: go-dsp's fft.FFTReal / fft.IFFT (mel/mel.go:95,116) run radix-2 for powers of two and
 // Bluestein's chirp-z otherwise.  The tuned kernels (gl_fft.hpp) exist for N = 256 ... 4096; everything else that is even and
 //   * a power of two up to 8192, or
-//   * any length up to 4096 (Bluestein through a power-of-two convolution of M >= 2N-1 <= 8192 points)
+//   * any length up to 8192 (Bluestein through a power-of-two convolution of >= 2N-1 points: up to 8192 of them in one piece, 16384 --
+//     for lengths above 4096 -- in two halves, dft_bluestein_split)
 // (odd lengths included: Bluestein does not care, and the reference's index arithmetic for an odd N is followed bin by bin)
 // runs here: one 1024-thread workgroup per frame, the frame as M complex doubles in LDS (up to 128 KiB of the CU's 160),
 // plain in-place radix-2 passes -- decimation in frequency forward (natural in, bit-reversed out) and decimation in time inverse
@@ -23,7 +24,9 @@ struct AnyTables {
     const v2d* tw;     // W_M^j = e^{-2 pi i j / M}, j < M/2
     const v2d* chirp;  // Bluestein: w[n] = e^{-i pi n^2 / N}, n < N
     const v2d* bhat;   // Bluestein: FFT_M of b[n] = conj(w[|n|]) (wrapped), in the bit-reversed order fft_dif leaves
-    int M, logM, bluestein;
+                       // (split form, bluestein == 2: FFT_2M of b, its even bins [M] then its odd bins [M], each in that order)
+    const v2d* omega;  // split form only: W_2M^n = e^{-i pi n / M}, n < M
+    int M, logM, bluestein;   // bluestein: 0 power of two, 1 Bluestein through an M-point convolution, 2 through a 2M-point one in two halves
 };
 constexpr int kAnyThreads = 1024;
 
@@ -80,6 +83,51 @@ __device__ void dft_bluestein(v2d* buf, int N, const AnyTables& at) {
     __syncthreads();
 }
 
+// The same for 4096 < N <= 8192 (not a power of two): the convolution needs 2N-1 <= 16384 points, 256 KB of complex doubles -- more than
+// a CU's LDS.  The zero-padded input fills only the lower half of those 2M points (N <= M = 8192), so one decimation-in-frequency step
+// splits FFT_2M(a) into two M-point transforms of the SAME M inputs -- even bins: FFT_M(a), odd bins: FFT_M(a[n] W_2M^n) -- and the
+// inverse, of which only the first N outputs are wanted, is z[m] = (E[m] + conj(W_2M^m) O[m]) / 2M with E, O the M-point inverse
+// transforms of the even / odd bins.  Four M-point FFTs in the one 128 KB buffer; the input and the even half's result wait in
+// registers (8 + 8 complex doubles per thread).
+__device__ void dft_bluestein_split(v2d* buf, int N, const AnyTables& at) {
+    const int M = at.M;
+    constexpr int PER = 8192 / kAnyThreads;           // M == 8192 here
+    v2d a[PER], e[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) { const int n = threadIdx.x + kAnyThreads * i; a[i] = n < N ? cmuld(buf[n], at.chirp[n]) : v2d{0.0, 0.0}; }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) { const int n = threadIdx.x + kAnyThreads * i; buf[n] = half ? cmuld(a[i], at.omega[n]) : a[i]; }
+        __syncthreads();
+        fft_dif<false>(buf, at);
+        const v2d* bh = at.bhat + (size_t)half * M;
+        for (int i = threadIdx.x; i < M; i += kAnyThreads) buf[i] = cmuld(buf[i], bh[i]);
+        __syncthreads();
+        fft_dit<true>(buf, at);
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < PER; i++) e[i] = buf[threadIdx.x + kAnyThreads * i];
+            __syncthreads();
+        }
+    }
+    const double sc = 1.0 / (2.0 * (double)M);
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int k = threadIdx.x + kAnyThreads * i;
+        if (k < N) {
+            const v2d z = e[i] + cmuld(buf[k], conjd(at.omega[k]));
+            const v2d c = cmuld(z, at.chirp[k]);
+            buf[k] = v2d{c.x * sc, c.y * sc};
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void dft_any(v2d* buf, int N, const AnyTables& at) {   // forward DFT_N of a length that is not a power of two
+    if (at.bluestein == 2) dft_bluestein_split(buf, N, at); else dft_bluestein(buf, N, at);
+}
+
 __device__ __forceinline__ v2d unit_phase_any(v2d x) {   // cmplx.Phase(0) = 0 -> (1, 0) (mel/mel.go:100-101)
     const double big = fmax(fabs(x.x), fabs(x.y));
     if (!(big > 0.0)) return v2d{1.0, 0.0};
@@ -105,7 +153,7 @@ __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __rest
     const double* xs = x + frame_xoff[frame];
     for (int n = threadIdx.x; n < N; n += kAnyThreads) buf[n] = v2d{xs[n] * window[n], 0.0};   // mel/mel.go:88-94
     __syncthreads();
-    if (at.bluestein) dft_bluestein(buf, N, at); else fft_dif<false>(buf, at);                   // fft.FFTReal, mel/mel.go:95
+    if (at.bluestein) dft_any(buf, N, at); else fft_dif<false>(buf, at);                         // fft.FFTReal, mel/mel.go:95
     auto pos = [&](int k) { return at.bluestein ? k : (int)bitrev((unsigned)k, logM); };
     if (MODE == kAnyToMel) {
         double* o = out + frame * (H + 1);
@@ -134,7 +182,7 @@ __global__ __launch_bounds__(kAnyThreads) void k_any_frames(const double* __rest
     if (at.bluestein) {   // inverse DFT = conj(forward DFT(conj(.)))
         for (int k = threadIdx.x; k < N; k += kAnyThreads) buf[k] = conjd(buf[k]);
         __syncthreads();
-        dft_bluestein(buf, N, at);
+        dft_any(buf, N, at);
     } else {
         fft_dit<true>(buf, at);
     }

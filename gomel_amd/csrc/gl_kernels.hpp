@@ -49,11 +49,10 @@ struct DevTables {
         default:   { constexpr int NN = 256;  __VA_ARGS__; } break; \
     }
 static inline bool gomel_supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-// what gl_any.hpp covers besides: powers of two up to 8192, and any length (odd ones too) up to 4096 (Bluestein, M <= 8192)
+// what gl_any.hpp covers besides: every other length (odd ones too) up to 8192 (radix-2; Bluestein, above 4096 in its split form)
 static inline bool gomel_generic_n(int n) {
     if (n < 4 || gomel_supported_n(n)) return false;
-    const bool pow2 = (n & (n - 1)) == 0;
-    return pow2 ? n <= 8192 : n <= 4096;
+    return n <= 8192;
 }
 
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {

@@ -236,38 +236,48 @@ template <class V> static void fill_twiddles(int N, int R1, int R2, std::vector<
 static int upload_tables_generic(gomel_handle* h) {
     const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
     const bool pow2 = (N & (N - 1)) == 0;
-    int M = 1, logM = 0;
-    while (M < (pow2 ? N : 2 * N - 1)) { M <<= 1; logM++; }
-    std::vector<v2d> tw((size_t)M / 2), chirp(pow2 ? 0 : (size_t)N), bhat(pow2 ? 0 : (size_t)M);
+    int Mc = 1, logMc = 0;                              // the convolution length of Bluestein: >= 2N - 1
+    while (Mc < (pow2 ? N : 2 * N - 1)) { Mc <<= 1; logMc++; }
+    const bool split = !pow2 && Mc > 8192;              // 16384 points do not fit a CU's LDS: two 8192-point halves (dft_bluestein_split)
+    const int M = split ? Mc / 2 : Mc, logM = split ? logMc - 1 : logMc;   // what the device's FFT routines run on
+    std::vector<v2d> tw((size_t)M / 2), chirp(pow2 ? 0 : (size_t)N), bhat(pow2 ? 0 : (size_t)Mc), omega(split ? (size_t)M : 0);
     for (int j = 0; j < M / 2; j++) { const double a = -2.0 * M_PI * (double)j / (double)M; tw[j] = v2d{std::cos(a), std::sin(a)}; }
+    for (size_t n = 0; n < omega.size(); n++) { const double a = -M_PI * (double)n / (double)M; omega[n] = v2d{std::cos(a), std::sin(a)}; }
     if (!pow2) {
         auto w = [&](int64_t n) { const double a = -M_PI * (double)((n * n) % (2 * (int64_t)N)) / (double)N; return v2d{std::cos(a), std::sin(a)}; };   // e^{-i pi n^2 / N}
         for (int n = 0; n < N; n++) chirp[n] = w(n);
-        std::vector<v2d> b((size_t)M, v2d{0.0, 0.0});
-        for (int n = 0; n < N; n++) { const v2d c = w(n); b[n] = v2d{c.x, -c.y}; if (n) b[M - n] = b[n]; }
-        // host FFT_M of b, decimation in frequency (the device's fft_dif): the result is already in its bit-reversed order
-        for (int s = 0; s < logM; s++) {
-            const int half = M >> (s + 1);
-            for (int idx = 0; idx < M / 2; idx++) {
-                const int grp = idx >> (logM - 1 - s), pos = idx & (half - 1), i0 = (grp << (logM - s)) + pos, i1 = i0 + half;
-                const v2d a = b[i0], c = b[i1], t = tw[(size_t)pos << s], d = v2d{a.x - c.x, a.y - c.y};
+        std::vector<v2d> b((size_t)Mc, v2d{0.0, 0.0}), twc((size_t)Mc / 2);
+        for (int j = 0; j < Mc / 2; j++) { const double a = -2.0 * M_PI * (double)j / (double)Mc; twc[j] = v2d{std::cos(a), std::sin(a)}; }
+        for (int n = 0; n < N; n++) { const v2d c = w(n); b[n] = v2d{c.x, -c.y}; if (n) b[Mc - n] = b[n]; }
+        // host FFT_Mc of b, decimation in frequency (the device's fft_dif): the result is already in its bit-reversed order
+        for (int s = 0; s < logMc; s++) {
+            const int half = Mc >> (s + 1);
+            for (int idx = 0; idx < Mc / 2; idx++) {
+                const int grp = idx >> (logMc - 1 - s), pos = idx & (half - 1), i0 = (grp << (logMc - s)) + pos, i1 = i0 + half;
+                const v2d a = b[i0], c = b[i1], t = twc[(size_t)pos << s], d = v2d{a.x - c.x, a.y - c.y};
                 b[i0] = v2d{a.x + c.x, a.y + c.y};
                 b[i1] = v2d{d.x * t.x - d.y * t.y, d.x * t.y + d.y * t.x};
             }
         }
-        bhat = b;
+        if (!split) bhat = b;
+        else {
+            // b[bitrev_Mc(k)] = Bhat[k].  Bin k = 2r + p (p = 0 even, 1 odd) sits at bitrev_Mc(k) = p * M + bitrev_M(r): the lower half of the
+            // bit-reversed array IS the even bins in the order an M-point fft_dif leaves them, the upper half the odd bins likewise.
+            bhat = b;
+        }
     }
     std::vector<float> wf(N);
     for (int i = 0; i < N; i++) wf[i] = (float)h->window[i];
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_win = carve((size_t)N * 4), o_wind = carve((size_t)N * 8), o_undo = carve((size_t)C * sizeof(BinRow)), o_dom = carve((size_t)K * sizeof(BinRow)),
-                 o_tw = carve(tw.size() * 16), o_ch = carve(chirp.size() * 16 + 16), o_bh = carve(bhat.size() * 16 + 16);
+                 o_tw = carve(tw.size() * 16), o_ch = carve(chirp.size() * 16 + 16), o_bh = carve(bhat.size() * 16 + 16), o_om = carve(omega.size() * 16 + 16);
     std::vector<char> host(off, 0);
     memcpy(&host[o_win], wf.data(), (size_t)N * 4); memcpy(&host[o_wind], h->window.data(), (size_t)N * 8);
     memcpy(&host[o_undo], h->undo.data(), (size_t)C * sizeof(BinRow)); memcpy(&host[o_dom], h->dom.data(), (size_t)K * sizeof(BinRow));
     memcpy(&host[o_tw], tw.data(), tw.size() * 16);
     if (!pow2) { memcpy(&host[o_ch], chirp.data(), chirp.size() * 16); memcpy(&host[o_bh], bhat.data(), bhat.size() * 16); }
+    if (split) memcpy(&host[o_om], omega.data(), omega.size() * 16);
     if (!h->d_blob) HIPCHK(hipMalloc(&h->d_blob, off));
     HIPCHK(hipMemcpy(h->d_blob, host.data(), off, hipMemcpyHostToDevice));
     char* d = (char*)h->d_blob;
@@ -275,7 +285,8 @@ static int upload_tables_generic(gomel_handle* h) {
     h->dt.window = (const float*)(d + o_win); h->dt.windowd = (const double*)(d + o_wind);
     h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
     h->dt.any.tw = (const v2d*)(d + o_tw); h->dt.any.chirp = (const v2d*)(d + o_ch); h->dt.any.bhat = (const v2d*)(d + o_bh);
-    h->dt.any.M = M; h->dt.any.logM = logM; h->dt.any.bluestein = pow2 ? 0 : 1;
+    h->dt.any.omega = (const v2d*)(d + o_om);
+    h->dt.any.M = M; h->dt.any.logM = logM; h->dt.any.bluestein = pow2 ? 0 : split ? 2 : 1;
     if ((size_t)M * 16 > 64 * 1024) {   // the frame lives in LDS: up to 128 KiB of the CU's 160
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<glany::kAnyGl>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glany::k_any_frames<glany::kAnyToMel>), hipFuncAttributeMaxDynamicSharedMemorySize, M * 16));

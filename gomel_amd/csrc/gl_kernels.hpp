@@ -176,10 +176,11 @@ template <class InT> GL_DEV double apply_row_exp(const BinRow r, const InT* __re
     for (int k = r.lo; k < r.hi; k++) tot += exp((double)m[2 * k + c]);
     return tot / r.div;
 }
-__global__ __launch_bounds__(256) void k_mel_to_mag_nat(const double* __restrict__ mel, const BinRow* __restrict__ undo, double* __restrict__ mag,
+template <class InT>
+__global__ __launch_bounds__(256) void k_mel_to_mag_nat(const InT* __restrict__ mel, const BinRow* __restrict__ undo, double* __restrict__ mag,
                                                         double* __restrict__ nyq, int K, int H, double tune_add, double tune_mul) {
     const int64_t f = blockIdx.x;
-    const double* m = mel + f * (int64_t)K * 2;
+    const InT* m = mel + f * (int64_t)K * 2;
     for (int k = threadIdx.x; k < H; k += blockDim.x) {
         const BinRow r = undo[k];
         mag[f * H + k] = fabs((apply_row_exp(r, m, 0) - tune_add) / tune_mul);                      // mel/impl.go:396-397, channel 0 -> bin k

@@ -833,11 +833,13 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         if (b->precise) {   // fp64 generic kernels end to end
             if (h->generic) {
                 if (b->direct) hipLaunchKernelGGL(k_mag_direct_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, b->d_magd, b->d_nyqd, b->d_midd, N / 2, N & 1);
-                else hipLaunchKernelGGL(k_mel_to_mag_nat, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
+                else if (b->io32) hipLaunchKernelGGL(k_mel_to_mag_nat<float>, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel32, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
+                else hipLaunchKernelGGL(k_mel_to_mag_nat<double>, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
             }
             else if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
             else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
-            hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
+            if (b->io32) hipLaunchKernelGGL((k_init_x<double, float>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x032, b->d_xd[0]);   // (generic lengths with float host buffers)
+            else hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
             if (b->mixed_k) {   // the fp32 kernel's magnitudes: the same fp64 values, rounded once
                 if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
                 else HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel64, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
@@ -901,7 +903,8 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                                    b->d_xd[curd ^ 1], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_spec, b->total_frames, N, h->dt.windowd, h->dt.any, b->d_midd);
             else if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
-            if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
+            if (!persist && b->io32) hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[curd], out32, b->total_len);
+            else if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
             if (b->fast == 1) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);   // (the any-hop form folds its tails itself)
             }   // !mixed_k
         } else {
@@ -1234,7 +1237,6 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // consecutive frames per stream and so only pays once there are enough frames to fill the chip (fused_min_frames); in
     // between (and for hops neither takes) every frame in parallel, two launches per iteration (generic kernels).
     b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
-    if (h->generic && b->io32) return GOMEL_ERR_UNSUPPORTED_N;
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
     // (every frame gathers its whole window from the covering frames, N/hop times the bytes of k_ola's single pass: beyond eight
     // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms

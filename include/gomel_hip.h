@@ -145,7 +145,7 @@ int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel
 /* fp32 host I/O: the same call for callers whose spectrograms and waveforms are float (an acoustic model's output,
  * a float PCM sink): half the PCIe bytes.  The log-mel values are taken as given (converted to double on the device, then the
  * fp64 table arithmetic of gomel_from_mel); the waveform is the fp32 result of the iteration without the final widening.
- * Not available on a handle in 64-bit precision mode (GOMEL_ERR_BAD_CONFIG). */
+ * Not available on a handle in 64-bit precision mode (GOMEL_ERR_BAD_CONFIG); the generic frame lengths take it (fp64 inside). */
 int gomel_from_mel_batch_f32(gomel_handle* h, size_t n_utt, const float* const* mel_pairs, const size_t* n_pairs,
                              const float* const* x0, const uint64_t* seeds, float* const* out, const size_t* out_cap);
 

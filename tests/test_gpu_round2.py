@@ -232,6 +232,17 @@ def test_fp32_host_io_entry(oracle):
     with pytest.raises(gomel_amd.GomelError):
         e.from_mel_batch_f32(mels, None, seeds)
     e.set_precision(32)
+    # the generic frame lengths take float host buffers too (their kernels are fp64 inside: the values are widened / narrowed once)
+    for N, hop, K in ((1000, 250, 40), (6000, 1500, 96)):
+        mg = mel_obj(dict(NumMels=K, MelFmax=8000.0, Window=hop, Resolut=N, GriffinLimIterations=3))
+        eg = mg.engine()
+        melsg = [oracle.random_logmel(f, K, seed=f).astype(np.float32) for f in (5, 9)]
+        x0g = [oracle.x0_splitmix(3 + i, N + (f - 1) * hop).astype(np.float32) for i, f in enumerate((5, 9))]
+        gotg = eg.from_mel_batch_f32(melsg, x0g, None)
+        refg = eg.from_mel_batch([mm.astype(np.float64) for mm in melsg], [x.astype(np.float64) for x in x0g], None)
+        for a, r in zip(gotg, refg):
+            assert a.dtype == np.float32 and rms(a.astype(np.float64) - r) < 1e-6 * max(1.0, rms(r))
+        eg.close()
 
 
 def test_multi_handle_batch_equals_one_handle(oracle):

@@ -274,8 +274,8 @@ def test_concurrent_persistent_launches_of_several_handles_share_the_chip(oracle
         (out,), tm = run(e, [mel], [8])
         assert tm["fast_path"] in (0, 2) and np.array_equal(out, ref)
         still_on += tm["fast_path"] == 2
-    assert still_on >= 3, still_on
         e.close()
+    assert still_on >= 3, still_on
 
 
 @pytest.mark.parametrize("bits,frames", [(32, [342]), (32, [400, 300]), (64, [342])])

@@ -56,6 +56,12 @@ def test_length_helpers_match_oracle(L, oracle):
     assert L.gomel_out_len(ctypes.byref(c), 342 * 192) == 440576        # 10 s @44.1 kHz
     assert L.gomel_out_len(ctypes.byref(c), 183 * 80) == 0               # not a multiple of NumMels
     assert L.gomel_out_len(ctypes.byref(c), 0) == 0
+    assert L.gomel_istft_row_len(ctypes.byref(c)) == 2049                # bins 0 ... N/2 of the exported ISTFT (mel/mel.go:98-108)
+    c.resolut = 4095
+    assert L.gomel_istft_row_len(ctypes.byref(c)) == 2049                # odd N = 2H+1: bins 0 ... H+1 keep their own magnitude (H = 2047)
+    c.resolut = 4096
+    assert L.gomel_istft_row_len(None) == 0
+    assert L.gomel_set_precision(None, 64) == 7 and L.gomel_set_precision_schedule(None, 30) == 7      # GOMEL_ERR_NULL
     for n, hop in [(441000, 1280), (19200, 1280), (19201, 1280), (100, 256), (3840, 256), (1, 2)]:
         want = len(oracle.pad(np.zeros(n), hop))
         assert L.gomel_pad_len(n, hop) == want

@@ -309,9 +309,7 @@ template <class S> struct IsSplitSync {
 };
 template <class S> GL_DEV void sync_reads_done(S& s) { if constexpr (IsSplitSync<S>::value) s.arrive(); else s(); }
 template <class S> GL_DEV void sync_before_write(S& s) { if constexpr (IsSplitSync<S>::value) s.wait(); }
-// behind a pass that ENDED with sync_reads_done, in front of writes of the caller's own: a plain callable synchronises once more (what
-// the kernels did before the split), a split-phase object only has to wait
-template <class S> GL_DEV void sync_area_free(S& s) { if constexpr (IsSplitSync<S>::value) s.wait(); else s(); }
+
 
 // ---------------------------------------------------------------------------------------------- forward
 // In: v[j] = z[t + T*j].  Out: v[0..7] = Z[bA + B3*r], v[8..15] = Z[bB + B3*r] with bA = t, bB = (t ? B3 - t : B3/2).

@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
                 }
             }
         }
-        sync();   // the inverse FFT's last reads of the exchange area are done
+        // (no barrier here: fft_inverse ends with one behind its last reads of the exchange area -- only butterflies follow it)
 #pragma unroll
         for (int j = 0; j < 16; j++) my[t + T * j] = acc[j];
         sync();
@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
                 }
             }
         }
-        sync_area_free(sync);   // the inverse FFT's last reads of the exchange area are done
+        // (no barrier here: fft_inverse ends with one behind its last reads of the exchange area -- only butterflies follow it)
 #pragma unroll
         for (int j = 0; j < 16; j++) my[t + T * j] = acc[j];
         sync();

@@ -3,6 +3,8 @@ import os, sys, math, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+from gomel_amd import _lib
+if os.environ.get("GOMEL_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["GOMEL_LIB"])   # A/B another build
 import gomel_amd
 def run(N, hop, K, U=256, F=400, I=20):
     PATH = int(os.environ.get("GOMEL_PATH", "0"))

@@ -384,9 +384,22 @@ def main():
     n_chunks = 1 if nb * frames < full else min(m_full + 1, nb)
     tm_chunk = resident(engine, fields, max(1, round(nb / m_full)), frames, first, 3)[1] if n_chunks > 1 else tm
 
+    # Everything below is measured BESIDE the headline (other configurations, other host buffers, the parity modes, the CPU leg): a
+    # failure in one of these legs is reported in the line (`leg_errors`) instead of costing the line itself.
+    leg_errors = {}
+
+    def guarded(name, fn):
+        try:
+            return fn()
+        except Exception as ex:  # noqa: BLE001 -- reported, not hidden: the JSON line carries it
+            leg_errors[name] = repr(ex)
+            return None
+
     side = rank == 0 and world == 1 and not args.no_single           # side measurements: N = 1 only
     single = pageable = cfg1 = f32io = None
-    if side:
+
+    def side_legs():
+        nonlocal single, pageable, cfg1
         if wl != "cfg2":
             d2, f2, u2, fr2, sr2 = WORKLOADS["cfg2"]
             e2 = build_engine(f2, local_rank)
@@ -399,15 +412,22 @@ def main():
         el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
         pageable = min(n_utt, BLOCK) * frames * 3 / el_p
         cfg1 = config1(local_rank)
+
+    if side:
+        guarded("side_measurements", side_legs)
     if rank == 0 and world == 1:                                      # float32 host I/O (half the PCIe bytes): informational, any workload
-        el_f, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, io32=True)
-        f32io = min(n_utt, BLOCK) * frames * 3 / el_f
+        def f32_leg():
+            el_f, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, io32=True)
+            return min(n_utt, BLOCK) * frames * 3 / el_f
+        f32io = guarded("float32_host_io", f32_leg)
     # The PARITY modes on the same clock (N = 1): the very batch of the fp32 leg through 64-bit mode (fp64 kernels throughout: the
     # mode that agrees with the reference's float64 arithmetic on every input) and through the precision schedule (the first
     # PARITY_SCHEDULE iterations fp64, the rest fp32) -- host to host like `value`, resident, their kernels' launch times.
     outs_by_mode = {"fp32": outs_last}
     precise = None
-    if rank == 0 and world == 1 and not args.no_precise:
+
+    def precise_legs():
+        nonlocal precise
         precise = {}
         N, hop = fields["Resolut"], fields["Window"]
         b32, b64 = algorithmic_bytes_per_frame_iter(N, hop), 2 * algorithmic_bytes_per_frame_iter(N, hop)
@@ -432,15 +452,21 @@ def main():
                 "kernel_fp32": {"name": "k_gl_fused", "launches_per_call": n32 // 3, "launch_ms": t32 * 1e3,
                                 "frac": tmp["frames"] * b32 / t32 / 1e9 / HBM_PEAK_GBS} if n32 else None,
             }
-        engine.set_precision_schedule(0)
+
+    if rank == 0 and world == 1 and not args.no_precise:
+        guarded("precise", precise_legs)
+        guarded("precise_reset", lambda: engine.set_precision_schedule(0))
     cpu = parity = None
     if rank == 0 and not args.no_cpu:
         mode = args.parity or "sample"                                # bounded (~25 s); --parity all checks every utterance of the batch (~80 s)
         if mode != "none":
-            cpu, parity_all = cpu_legs(fields, frames, mels_last, seeds_last, outs_by_mode, mode)
-            parity = parity_all.get("fp32")
-            for name in (precise or {}):
-                precise[name]["parity"] = parity_all.get(name)
+            got = guarded("cpu_baseline", lambda: cpu_legs(fields, frames, mels_last, seeds_last, outs_by_mode, mode))
+            if got is not None:
+                cpu, parity_all = got
+                parity = parity_all.get("fp32")
+                for name in (precise or {}):
+                    if name in parity_all:
+                        precise[name]["parity"] = parity_all[name]
         if world > 1:
             cpu = None                                                # the CPU baseline is an N = 1 figure
 
@@ -481,6 +507,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "precise": precise,
+            "leg_errors": leg_errors or None,
             "single_utterance": single,
             "config1_towav_png_2_iters": cfg1,
             "world_size": world, "backend": backend if world > 1 else None, "per_rank_frames_per_s": per_rank,

@@ -11,7 +11,8 @@ METRIC (SURVEY 8d / BASELINE.md): frames/s = frames pushed through all 60 Griffi
 gomel_from_mel_batch -- host fp64 log-mel in, host fp64 waveforms out, H2D and D2H INCLUDED, handle creation excluded.  A "step" is
 one such call over the rank's batch; W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, MAX
 over ranks.  The caller's buffers are pinned host memory (gomel_host_alloc: what a bulk Go caller would hand over); the same call
-through pageable buffers is reported beside it (`pageable_frames_per_s`), and the HBM-resident rate -- inputs already in HBM, output
+through pageable buffers is reported beside it (`pageable_frames_per_s`; the buffers are bound to the engine once, Engine.bind_buffers, as
+a C caller's pointer arrays are filled once), and the HBM-resident rate -- inputs already in HBM, output
 left in HBM -- as `resident_frames_per_s`.  The roofline block is about the dominant kernel: its launch time comes from HIP events
 on the library's stream in this run, its algorithmic bytes from SURVEY 8(d).
 
@@ -152,11 +153,22 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
         o[:] = 0.0                                                   # touched: what a caller's own slices are
     blocks = [(b0, min(nb, n_local - b0)) for b0 in range(0, n_local, nb)]
 
+    # the caller's buffers are bound once (Engine.bind_buffers: the pointer arrays a C / Go caller fills at start-up), so that a timed
+    # call is the C ABI call and the seeds -- not 0.5 ms of Python list handling per 256 utterances
+    bound = {}
+    if not io32:
+        for b0, cnt in blocks:
+            m0 = b0 if whole else 0
+            bound[(m0, cnt)] = engine.bind_buffers(mels[m0:m0 + cnt], outs[m0:m0 + cnt])
+
     def step():
         for b0, cnt in blocks:
             seeds = [1000 + first + b0 + u for u in range(cnt)]      # the seed of an utterance is its GLOBAL index
             m0 = b0 if whole else 0
-            call(mels[m0:m0 + cnt], None, seeds, outs[m0:m0 + cnt])
+            if io32:
+                call(mels[m0:m0 + cnt], None, seeds, outs[m0:m0 + cnt])
+            else:
+                engine.from_mel_batch_bound(bound[(m0, cnt)], seeds)
 
     for _ in range(warmup):
         step()

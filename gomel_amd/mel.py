@@ -218,6 +218,28 @@ class Engine:
                                               as_p(caps, ctypes.POINTER(ctypes.c_size_t))), "gomel_from_mel_batch")
         return [o[:L] for o, L in zip(outs, lens)]
 
+    def bind_buffers(self, mels, outs, x0s=None):
+        """For callers that reuse their buffers call after call (a serving loop, bench.py): validate the arrays and build the
+        pointer / length arrays of gomel_from_mel_batch ONCE -- what a C or Go caller does when it fills its `double**` arrays at
+        start-up.  Returns a BoundBuffers for from_mel_batch_bound; it keeps the arrays alive."""
+        return BoundBuffers(self, mels, outs, x0s)
+
+    def from_mel_batch_bound(self, bound, seeds=None):
+        """gomel_from_mel_batch on buffers bound with bind_buffers: no per-call marshalling beyond the seeds.  The waveforms land in
+        the bound `outs` (returned, trimmed to the output lengths)."""
+        if bound.engine is not self:
+            raise ValueError("buffers were bound to another engine")
+        n = bound.n
+        sp = None if seeds is None else np.array([int(s_) & (2 ** 64 - 1) for s_ in seeds], dtype=np.uint64)
+        if sp is not None and len(sp) != n:
+            raise ValueError("one seed per utterance")
+        dpp = ctypes.POINTER(c_double_p)
+        check(_lib.lib().gomel_from_mel_batch(self._h, n, bound.mp.ctypes.data_as(dpp), bound.npairs.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)),
+                                              None if bound.xp is None else bound.xp.ctypes.data_as(dpp),
+                                              None if sp is None else sp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), bound.op.ctypes.data_as(dpp),
+                                              bound.caps.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t))), "gomel_from_mel_batch")
+        return bound.views
+
     def target_magnitudes(self, mel_pairs):
         m = _as_pairs(mel_pairs)
         H = self.cfg.resolut // 2
@@ -465,6 +487,36 @@ class Mel:
             self.SampleRate = int(samplerate)
         codec.dumpwav(outputFile, owave, self.SampleRate)  # the reference drops this error (mel.go:235)
         return None
+
+
+class BoundBuffers:
+    """Caller-owned spectrogram / waveform (/ x0) arrays with the pointer arrays gomel_from_mel_batch takes, built once
+    (Engine.bind_buffers).  Holds references to the arrays: they cannot go away, or be resized, while bound."""
+
+    def __init__(self, engine, mels, outs, x0s=None):
+        ms = list(mels)
+        if any(not isinstance(m, np.ndarray) or m.dtype != np.float64 or m.ndim != 2 or m.shape[1] != 2 or not m.flags.c_contiguous for m in ms):
+            raise ValueError("mels must be C-contiguous float64 [n, 2] arrays (they are bound, not copied)")
+        K, N, hop = engine.cfg.num_mels, engine.cfg.resolut, engine.cfg.window
+        lens = [N + (len(m) // K - 1) * hop if len(m) and len(m) % K == 0 else 0 for m in ms]
+        os_ = list(outs)
+        if len(os_) != len(ms) or any(not isinstance(o, np.ndarray) or o.dtype != np.float64 or o.ndim != 1 or len(o) < L or not o.flags.c_contiguous
+                                      for o, L in zip(os_, lens)):
+            raise ValueError("outs must be C-contiguous float64 arrays of at least the output lengths")
+        xs = None
+        if x0s is not None:
+            xs = list(x0s)
+            if len(xs) != len(ms) or any(x is not None and (not isinstance(x, np.ndarray) or x.dtype != np.float64 or x.shape != (L,) or not x.flags.c_contiguous)
+                                         for x, L in zip(xs, lens)):
+                raise ValueError("x0s must be C-contiguous float64 arrays of the output lengths (or None)")
+        ptrs = lambda arrs: np.array([0 if a is None else a.__array_interface__["data"][0] for a in arrs], dtype=np.uintp)
+        self.engine, self.n = engine, len(ms)
+        self._keep = (ms, os_, xs)
+        self.mp, self.op = ptrs(ms), ptrs(os_)
+        self.xp = None if xs is None else ptrs(xs)
+        self.npairs = np.array([len(m) for m in ms], dtype=np.uintp)
+        self.caps = np.array([len(o) for o in os_], dtype=np.uintp)
+        self.views = [o[:L] for o, L in zip(os_, lens)]
 
 
 class _PinnedOwner:

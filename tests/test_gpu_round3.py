@@ -293,3 +293,30 @@ def test_host_to_host_call_in_the_parity_modes(oracle, coracle):
     eng.set_precision_schedule(0)
     o32 = eng.from_mel_batch(mels, None, seeds)
     assert max(rms(o32[u] - w) for u, w in zip(pick, want)) < RMS_TOL                                # 20 iterations: fp32 is still at 1e-6
+
+
+def test_bound_buffers_equal_the_marshalling_call(oracle):
+    """Engine.bind_buffers / from_mel_batch_bound: the pointer arrays of gomel_from_mel_batch built once for buffers a caller reuses
+    (bench.py's timed loop): same bits as the call that marshals every time, the waveforms land in the bound arrays, x0 arrays bind too."""
+    import gomel_amd
+    fields = dict(S, GriffinLimIterations=4)
+    m = mel_obj(fields)
+    eng = m.engine()
+    frames = [30, 7, 64, 12]
+    mels = [oracle.random_logmel(f, 80, seed=70 + i) for i, f in enumerate(frames)]
+    cfg = oracle.MelConfig(**fields)
+    outs = [np.zeros(oracle.out_len(cfg, len(mm)) + 5) for mm in mels]            # roomier than needed: the views are trimmed
+    b = eng.bind_buffers(mels, outs)
+    got = eng.from_mel_batch_bound(b, [3, 4, 5, 6])
+    ref = eng.from_mel_batch(mels, None, [3, 4, 5, 6])
+    assert all(np.array_equal(a, r) and a.base is not None for a, r in zip(got, ref))
+    assert all(np.array_equal(o[:len(r)], r) for o, r in zip(outs, ref))
+    x0s = [oracle.x0_splitmix(9 + i, len(r)) for i, r in enumerate(ref)]
+    bx = eng.bind_buffers(mels, outs, x0s)
+    gotx = eng.from_mel_batch_bound(bx)
+    refx = eng.from_mel_batch(mels, x0s, None)
+    assert all(np.array_equal(a, r) for a, r in zip(gotx, refx))
+    with pytest.raises(ValueError):
+        eng.bind_buffers(mels, outs[:2])
+    with pytest.raises(ValueError):
+        eng.bind_buffers([mm.astype(np.float32) for mm in mels], outs)

@@ -10,11 +10,16 @@ touches a GPU) and exits with its code.
 METRIC (SURVEY 8d / BASELINE.md): frames/s = frames pushed through all 60 Griffin-Lim iterations / wall time of
 gomel_from_mel_batch -- host fp64 log-mel in, host fp64 waveforms out, H2D and D2H INCLUDED, handle creation excluded.  A "step" is
 one such call over the rank's batch; W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, MAX
-over ranks.  The caller's buffers are pinned host memory (gomel_host_alloc: what a bulk Go caller would hand over); the same call
-through pageable buffers is reported beside it (`pageable_frames_per_s`; the buffers are bound to the engine once, Engine.bind_buffers, as
-a C caller's pointer arrays are filled once), and the HBM-resident rate -- inputs already in HBM, output
-left in HBM -- as `resident_frames_per_s`.  The roofline block is about the dominant kernel: its launch time comes from HIP events
-on the library's stream in this run, its algorithmic bytes from SURVEY 8(d).
+over ranks.  `value` is the DEFAULT precision mode -- the handle as gomel_create hands it over, no knob turned: the calibrated
+fp64-then-fp32 schedule (gomel_auto_fp64_iterations: 35 + 25 iterations at 60), the mode that agrees with the reference's float64
+arithmetic within 1e-4 RMS -- with TWO CALLS IN FLIGHT (gomel_from_mel_batch_submit / gomel_job_wait: every call one whole batch,
+the copies of one call beside the kernels of the other; two sets of output buffers).  Beside it: the same calls from a lone
+synchronous caller (`single_caller_frames_per_s`: the chunked call), the opt-in fp32 fast mode and fp64 throughout (`modes`), each
+with its own parity block.  The caller's buffers are pinned host memory (gomel_host_alloc: what a bulk Go caller would hand
+over); the same call through pageable buffers is `pageable_frames_per_s` (buffers bound to the engine once, Engine.bind_buffers, as
+a C caller's pointer arrays are filled once); inputs already in HBM and output left in HBM is `resident_frames_per_s`.  The
+roofline block is about the dominant kernel of the default mode (k_gl_fused_d, the fp64 iterations): its launch time comes from
+HIP events on the library's stream in this run, its algorithmic bytes from SURVEY 8(d).
 
 Workloads (BASELINE.json configs): cfg3 = configs[2], 256 x (192 mels x 400 frames) random log-mel, N 4096 / hop 1280, 60
 iterations (the configuration the roofline figure is quoted on; default at N = 1, weak scaling when forced at N > 1).  cfg5 =
@@ -54,7 +59,7 @@ STRONG = {"cfg5"}
 BLOCK = 256                     # utterances per gomel_from_mel_batch call
 MATERIALISE = 1024              # shards up to this many utterances are materialised whole on the host (configs[4] at 8 GPUs: 1024 per rank)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PARITY_SCHEDULE = 30            # iterations in fp64 before the fp32 kernel takes over (gomel_set_precision_schedule), see DESIGN.md section 2
+DEPTH = 2                       # calls in flight in the timed region (gomel_from_mel_batch_submit / gomel_job_wait)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
 
 
@@ -81,12 +86,13 @@ def build_engine(fields, device, tables=None):
 PATHS = ("generic", "fused", "persistent", "fused")      # gomel_timing.fast_path (3 = the fused kernel's any-hop form)
 
 
-def committed_traffic(workload, fast_path):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc passes (profiles/traffic.json): counters
-    cannot be read from inside the timed process, so this figure is a label from an earlier profile of the same kernel."""
+def committed_traffic(workload, kernel_key):
+    """HBM bytes per launch of a kernel ("fused", "fused_d", "persistent") from the COMMITTED rocprofv3 --pmc passes
+    (profiles/traffic.json): counters cannot be read from inside the timed process, so this figure is a label from an earlier
+    profile of the same kernel."""
     try:
         with open(TRAFFIC_JSON) as f:
-            e = json.load(f).get("%s:%s" % (workload, PATHS[fast_path]))
+            e = json.load(f).get("%s:%s" % (workload, kernel_key))
         return (None, None) if e is None else (e.get("hbm_bytes_per_launch"), "profiles/traffic.json [%s] (separate rocprofv3 --pmc passes, not this run)" % e.get("from", "?"))
     except (OSError, ValueError):
         return None, None
@@ -128,9 +134,12 @@ def go_probe():
 
 
 # ------------------------------------------------------------------------------------------------ the measured legs
-def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier, pinned=True, io32=False):
-    """The metric: K calls of gomel_from_mel_batch per BLOCK of the rank's shard, host buffers in, host buffers out.
-    (io32: the float32 host-I/O entry point, gomel_from_mel_batch_f32 -- an informational side figure, never `value`.)"""
+def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier, pinned=True, io32=False, depth=DEPTH):
+    """The metric: K steps of gomel_from_mel_batch per BLOCK of the rank's shard, host buffers in, host buffers out.
+    depth >= 2: that many calls in flight (submit / wait; two sets of output buffers where consecutive calls would otherwise share
+    one); depth 0: one synchronous (chunked) call after the other.  (io32: the float32 host-I/O entry point,
+    gomel_from_mel_batch_f32 -- an informational side figure, never `value`; synchronous.)"""
+    import collections
     import gomel_amd
     import torch
     K = fields["NumMels"]
@@ -139,6 +148,8 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     # geometry); a larger one re-uses one block of BLOCK utterances' buffers with the shard's own seeds
     whole = n_local <= MATERIALISE
     nmat = n_local if whole else nb
+    if io32:
+        depth = 0
     dt = np.float32 if io32 else np.float64
     alloc = (lambda shape: gomel_amd.host_alloc(shape, dtype=dt)) if pinned else (lambda shape: np.zeros(shape, dtype=dt))
     call = engine.from_mel_batch_f32 if io32 else engine.from_mel_batch
@@ -148,10 +159,13 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
         a[:] = src
         mels.append(a)
     L = engine.out_len(frames * K)
-    outs = [alloc(L) for _ in range(nmat)]
-    for o in outs:
-        o[:] = 0.0                                                   # touched: what a caller's own slices are
     blocks = [(b0, min(nb, n_local - b0)) for b0 in range(0, n_local, nb)]
+    # calls in flight must not share output buffers: a second set where consecutive calls would land in the same one
+    nsets = 2 if depth >= 2 and (not whole or len(blocks) == 1) else 1
+    outs = [[alloc(L) for _ in range(nmat)] for _ in range(nsets)]
+    for st in outs:
+        for o in st:
+            o[:] = 0.0                                               # touched: what a caller's own slices are
 
     # the caller's buffers are bound once (Engine.bind_buffers: the pointer arrays a C / Go caller fills at start-up), so that a timed
     # call is the C ABI call and the seeds -- not 0.5 ms of Python list handling per 256 utterances
@@ -159,30 +173,41 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     if not io32:
         for b0, cnt in blocks:
             m0 = b0 if whole else 0
-            bound[(m0, cnt)] = engine.bind_buffers(mels[m0:m0 + cnt], outs[m0:m0 + cnt])
+            for k in range(nsets):
+                bound[(m0, cnt, k)] = engine.bind_buffers(mels[m0:m0 + cnt], outs[k][m0:m0 + cnt])
+    counter = [0]
 
-    def step():
-        for b0, cnt in blocks:
-            seeds = [1000 + first + b0 + u for u in range(cnt)]      # the seed of an utterance is its GLOBAL index
-            m0 = b0 if whole else 0
-            if io32:
-                call(mels[m0:m0 + cnt], None, seeds, outs[m0:m0 + cnt])
-            else:
-                engine.from_mel_batch_bound(bound[(m0, cnt)], seeds)
+    def run(n_steps):
+        q = collections.deque()
+        for _ in range(n_steps):
+            for b0, cnt in blocks:
+                seeds = [1000 + first + b0 + u for u in range(cnt)]  # the seed of an utterance is its GLOBAL index
+                m0 = b0 if whole else 0
+                k = counter[0] % nsets
+                counter[0] += 1
+                if io32:
+                    call(mels[m0:m0 + cnt], None, seeds, outs[0][m0:m0 + cnt])
+                elif depth >= 2:
+                    q.append(engine.submit_bound(bound[(m0, cnt, k)], seeds))
+                    if len(q) >= depth:
+                        q.popleft().wait()
+                else:
+                    engine.from_mel_batch_bound(bound[(m0, cnt, k)], seeds)
+        while q:
+            q.popleft().wait()
 
-    for _ in range(warmup):
-        step()
+    run(warmup)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run(steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     last_b0, last_cnt = blocks[-1]
     m0 = last_b0 if whole else 0
-    return elapsed, mels[m0:m0 + last_cnt], [1000 + first + last_b0 + u for u in range(last_cnt)], [np.array(o) for o in outs[m0:m0 + last_cnt]]
+    k_last = (counter[0] - 1) % nsets
+    return elapsed, mels[m0:m0 + last_cnt], [1000 + first + last_b0 + u for u in range(last_cnt)], [np.array(o) for o in outs[k_last][m0:m0 + last_cnt]]
 
 
 def resident(engine, fields, n_utt, frames, first, steps):
@@ -259,7 +284,7 @@ def cpu_legs(fields, frames, mels, seeds, outs_by_mode, mode):
     """ONE run of the C restatement of the reference algorithm (oracle/gomel_oracle.c) serves two purposes, outside every timed
     region: it is the reported CPU baseline (utterance-parallel host threads, the very utterances the GPU just computed) and it
     is the checker of those GPU results (`parity`), for every precision mode that was timed (`outs_by_mode`: name -> waveforms
-    of the same utterances).  `mode`: all | sample | none."""
+    of the same utterances: the default mode, fp32, fp64).  `mode`: all | sample | none."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gomel_oracle as go
     import oracle_c
@@ -300,8 +325,8 @@ def cpu_legs(fields, frames, mels, seeds, outs_by_mode, mode):
                         "worst_utterances": [int(pick[i]) for i in np.argsort(-err)[:3]], "signal_rms": sig,
                         "oracle": "oracle/gomel_oracle.c (fp64 restatement, parity unpinned: no Go toolchain / reference vectors)"}
     if "fp32" in parity:
-        parity["fp32"]["note"] = ("fp32 kernels vs fp64 reference arithmetic on iid-random (inconsistent) spectrograms: see DESIGN.md 'Parity in numbers'; "
-                                  "the parity modes (64-bit mode, precision schedule) meet the tolerance on every utterance: `precise` block of the N = 1 line")
+        parity["fp32"]["note"] = ("the opt-in fast mode: fp32 kernels vs fp64 reference arithmetic on iid-random (inconsistent) spectrograms leaves ~1 % of "
+                                  "60-iteration utterances beyond the tolerance (DESIGN.md 'Parity in numbers'); the default mode and fp64 throughout must show 0")
     return cpu, parity
 
 
@@ -317,6 +342,33 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+MODES = {   # name -> (gomel_set_precision_schedule argument, what it is)
+    "default": ("auto", "the handle as gomel_create returns it: the calibrated schedule gomel_auto_fp64_iterations(cfg, I) -- fp64 first, fp32 after"),
+    "fp32": (0, "gomel_set_precision(h, 32): fp32 kernels for every iteration, the opt-in fast mode"),
+    "fp64": (-1, "gomel_set_precision(h, 64): fp64 kernels for every iteration"),
+}
+
+
+def kernel_block(tm, fields, I):
+    """Launch times and roofline fractions of the fused kernels of one resident timing (three timed calls summed)."""
+    N, hop = fields["Resolut"], fields["Window"]
+    b32 = algorithmic_bytes_per_frame_iter(N, hop)
+    n64, n32 = tm["iter64_launches"], tm["iter_launches"] - tm["iter64_launches"]
+    out = {}
+    if tm["fast_path"] == 2:       # persistent kernel: one launch = all I iterations
+        t = tm["dom_ms"] / max(1, tm["iter_launches"]) * 1e-3
+        out["k_gl_persist"] = {"launch_ms": t * 1e3, "frac": tm["frames"] * b32 * I / t / 1e9 / HBM_PEAK_GBS, "launches_per_call": 1}
+        return out
+    if n64:
+        t64 = tm["dom64_ms"] / n64 * 1e-3
+        out["k_gl_fused_d"] = {"launch_ms": t64 * 1e3, "launches_per_call": n64 // 3, "frac": tm["frames"] * b32 / t64 / 1e9 / HBM_PEAK_GBS,
+                               "frac_own_fp64_bytes": tm["frames"] * 2 * b32 / t64 / 1e9 / HBM_PEAK_GBS}
+    if n32:
+        t32 = (tm["dom_ms"] - tm["dom64_ms"]) / n32 * 1e-3
+        out[tm["dom_kernel"]] = {"launch_ms": t32 * 1e3, "launches_per_call": n32 // 3, "frac": tm["frames"] * b32 / t32 / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,26 +376,33 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: cfg3 on one GPU, cfg5 (sharded corpus) on several")
     ap.add_argument("--utts-per-gpu", type=int, default=0)
+    ap.add_argument("--mode", default="default", choices=sorted(MODES), help="precision mode `value` is measured in (default: the library's default)")
+    ap.add_argument("--depth", type=int, default=DEPTH, help="calls in flight in the timed region (0 or 1: one synchronous call after the other)")
     ap.add_argument("--parity", default=None, choices=["all", "sample", "none"], help="oracle check of the timed batch: a ~25 s sample of its utterances (default), all of them, or none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (baseline + parity)")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurements (configs[1], configs[0], pageable buffers)")
-    ap.add_argument("--no-precise", action="store_true", help="skip the parity modes' legs (64-bit mode, precision schedule)")
+    ap.add_argument("--no-modes", "--no-precise", dest="no_modes", action="store_true", help="skip the other precision modes' legs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    backend = os.environ.get("GOMEL_BENCH_BACKEND", "nccl")
+    # BEFORE anything touches the GPU: bind this rank to the CPUs of its GPU's NUMA node (pinned buffers are then first-touched in
+    # memory local to the GPU's root port).  The bus ids come from a rocm-smi child process; counting devices does not initialise HIP.
+    from gomel_amd import dist as gdist
+    import torch
+    ndev = max(1, torch.cuda.device_count())
     # One rank per GPU.  GOMEL_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: collectives run
     # on CPU tensors and ranks wrap around the visible devices (the driver's multi-GPU runs use the default, nccl = RCCL).
-    backend = os.environ.get("GOMEL_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    local_rank = local_rank % ndev if backend != "nccl" else local_rank
+    affinity = {"bound": False, "why": "GOMEL_BENCH_NO_BIND"} if os.environ.get("GOMEL_BENCH_NO_BIND") else gdist.bind_to_gpu_numa_node(local_rank)
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
@@ -357,6 +416,13 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def gather(v):
+        if world == 1:
+            return [v]
+        got = [None] * world
+        dist.all_gather_object(got, v)
+        return got
+
     wl = args.workload or ("cfg3" if world == 1 else "cfg5")
     desc, fields, n_utt, frames, sr = WORKLOADS[wl]
     strong = wl in STRONG
@@ -368,36 +434,43 @@ def main():
     if args.utts_per_gpu > 0:
         n_utt = args.utts_per_gpu
         first = rank * n_utt
+    N, hop, I, K = fields["Resolut"], fields["Window"], fields["GriffinLimIterations"], fields["NumMels"]
 
     # table blob ("mel basis"): rank 0 builds, broadcast over RCCL/xGMI, every rank creates its handle from it
-    from gomel_amd import dist as gdist
     t0 = time.perf_counter()
     engine = gdist.create_engine_broadcast(lambda tables=None: build_engine(fields, local_rank, tables), rank, world, device=coll_dev)
     bcast_s = time.perf_counter() - t0
+    k_default = engine.fp64_iterations()                               # the handle untouched: what the default call will do
 
-    elapsed_local, mels_last, seeds_last, outs_last = host_to_host(engine, fields, n_utt, frames, first, args.steps, args.warmup, barrier)
+    def set_mode(name):
+        engine.set_precision_schedule(MODES[name][0])
+
+    def dtype_of(name):
+        k = engine.fp64_iterations()
+        return "f32" if k == 0 else "f64" if k >= I else "f64x%d+f32x%d" % (k, I - k)
+
+    if args.mode != "default":
+        set_mode(args.mode)
+    depth = args.depth if args.depth >= 2 else 0
+    elapsed_local, mels_last, seeds_last, outs_last = host_to_host(engine, fields, n_utt, frames, first, args.steps, args.warmup, barrier, depth=depth)
     elapsed = elapsed_local
-    per_rank = [n_utt * frames * args.steps / elapsed_local]
     if world > 1:
         t = torch.tensor([elapsed_local], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        gathered = [None] * world
-        dist.all_gather_object(gathered, per_rank[0])
-        per_rank = gathered
+    L_out = engine.out_len(frames * K)
+    mine = {"rank": rank, "frames_per_s": n_utt * frames * args.steps / elapsed_local,
+            "h2d_GBps": n_utt * frames * K * 16 * args.steps / elapsed_local / 1e9, "d2h_GBps": n_utt * L_out * 8 * args.steps / elapsed_local / 1e9,
+            "table_broadcast_s": bcast_s, "cpu_affinity": affinity, "device": local_rank}
+    per_rank = gather(mine)
 
-    # device-side figures (outside the timed region): one BLOCK resident in HBM
+    # device-side figures (outside the timed region): one BLOCK resident in HBM, HIP events around every launch of the iteration kernels
     res_fps, tm = resident(engine, fields, min(n_utt, BLOCK), frames, first, max(3, min(args.steps, 10)))
-    # inside the timed region the library cuts a call into chunks (from_mel_batch_guarded in gomel_hip.hip: m = frames / 12288 full
-    # chunks' worth at Resolut 4096, / 32768 below, cut half : full x (m-1) : half): the same kernel at a full chunk's size
-    nb = min(n_utt, BLOCK)
-    full = 12288 if fields["Resolut"] >= 4096 else 32768
-    m_full = min(16, max(1, nb * frames // full))
-    n_chunks = 1 if nb * frames < full else min(m_full + 1, nb)
-    tm_chunk = resident(engine, fields, max(1, round(nb / m_full)), frames, first, 3)[1] if n_chunks > 1 else tm
+    kernels = kernel_block(tm, fields, I)
+    dtype = dtype_of(args.mode)
 
-    # Everything below is measured BESIDE the headline (other configurations, other host buffers, the parity modes, the CPU leg): a
-    # failure in one of these legs is reported in the line (`leg_errors`) instead of costing the line itself.
+    # Everything below is measured BESIDE the headline (a lone synchronous caller, the other precision modes, other configurations,
+    # other host buffers, the CPU leg): a failure in one of these legs is reported in the line (`leg_errors`) instead of costing the line.
     leg_errors = {}
 
     def guarded(name, fn):
@@ -407,130 +480,140 @@ def main():
             leg_errors[name] = repr(ex)
             return None
 
-    side = rank == 0 and world == 1 and not args.no_single           # side measurements: N = 1 only
+    solo = rank == 0 and world == 1
+    outs_by_mode = {args.mode: outs_last}
+    single_caller = None
+    if solo:
+        def single_caller_leg():
+            el, _, _, _ = host_to_host(engine, fields, n_utt, frames, first, max(3, args.steps // 3), 1, lambda: None, depth=0)
+            return n_utt * frames * max(3, args.steps // 3) / el
+        single_caller = guarded("single_caller", single_caller_leg)
+
+    modes = {}
+
+    def mode_legs():
+        for name in MODES:
+            if name == args.mode:
+                continue
+            set_mode(name)
+            psteps = max(3, args.steps // 3)
+            el, _, _, outs_p = host_to_host(engine, fields, n_utt, frames, first, psteps, 1, lambda: None, depth=depth)
+            el1, _, _, _ = host_to_host(engine, fields, n_utt, frames, first, 3, 1, lambda: None, depth=0)
+            rfps, tmp = resident(engine, fields, min(n_utt, BLOCK), frames, first, 3)
+            outs_by_mode[name] = outs_p
+            modes[name] = {"what": MODES[name][1], "dtype": dtype_of(name), "value": n_utt * frames * psteps / el, "unit": "frames/s", "steps": psteps,
+                           "ms_per_step": el / psteps * 1e3, "timed_region": "as `value`: %s" % ("%d calls in flight" % depth if depth else "synchronous calls"),
+                           "single_caller_frames_per_s": n_utt * frames * 3 / el1, "resident_frames_per_s": rfps, "kernels": kernel_block(tmp, fields, I)}
+
+    if solo and not args.no_modes:
+        guarded("modes", mode_legs)
+    if solo:
+        guarded("mode_reset", lambda: set_mode(args.mode))
+
+    side = solo and not args.no_single                                # side measurements: N = 1 only
     single = pageable = cfg1 = f32io = None
 
     def side_legs():
         nonlocal single, pageable, cfg1
         if wl != "cfg2":
             d2, f2, u2, fr2, sr2 = WORKLOADS["cfg2"]
-            e2 = build_engine(f2, local_rank)
-            fps2, tm2 = resident(e2, f2, u2, fr2, 0, 20)
-            el2, _, _, _ = host_to_host(e2, f2, u2, fr2, 0, 20, 2, lambda: None)
-            single = {"workload": d2, "resident_frames_per_s": fps2, "resident_ms_per_utterance": u2 * fr2 / fps2 * 1e3,
-                      "host_to_host_ms_per_utterance": el2 / 20 * 1e3, "real_time_factor_host_to_host": u2 * fr2 * 20 / el2 * f2["Window"] / sr2,
-                      "kernel_path": PATHS[tm2["fast_path"]]}
-            e2.close()
-        el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False)
+            single = {"workload": d2}
+            for name in ("default", "fp32"):
+                e2 = build_engine(f2, local_rank)
+                e2.set_precision_schedule(MODES[name][0])
+                fps2, tm2 = resident(e2, f2, u2, fr2, 0, 20)
+                el2, _, _, _ = host_to_host(e2, f2, u2, fr2, 0, 20, 2, lambda: None, depth=0)
+                single[name] = {"fp64_iterations": e2.fp64_iterations(), "resident_frames_per_s": fps2, "resident_ms_per_utterance": u2 * fr2 / fps2 * 1e3,
+                                "host_to_host_ms_per_utterance": el2 / 20 * 1e3, "real_time_factor_host_to_host": u2 * fr2 * 20 / el2 * f2["Window"] / sr2,
+                                "kernel_path": PATHS[tm2["fast_path"]]}
+                e2.close()
+        el_p, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, pinned=False, depth=0)
         pageable = min(n_utt, BLOCK) * frames * 3 / el_p
         cfg1 = config1(local_rank)
 
     if side:
         guarded("side_measurements", side_legs)
-    if rank == 0 and world == 1:                                      # float32 host I/O (half the PCIe bytes): informational, any workload
+    if solo:                                                          # float32 host I/O (half the PCIe bytes): informational, any workload
         def f32_leg():
             el_f, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, io32=True)
             return min(n_utt, BLOCK) * frames * 3 / el_f
         f32io = guarded("float32_host_io", f32_leg)
-    # The PARITY modes on the same clock (N = 1): the very batch of the fp32 leg through 64-bit mode (fp64 kernels throughout: the
-    # mode that agrees with the reference's float64 arithmetic on every input) and through the precision schedule (the first
-    # PARITY_SCHEDULE iterations fp64, the rest fp32) -- host to host like `value`, resident, their kernels' launch times.
-    outs_by_mode = {"fp32": outs_last}
-    precise = None
 
-    def precise_legs():
-        nonlocal precise
-        precise = {}
-        N, hop = fields["Resolut"], fields["Window"]
-        b32, b64 = algorithmic_bytes_per_frame_iter(N, hop), 2 * algorithmic_bytes_per_frame_iter(N, hop)
-        for name, sched in (("fp64", -1), ("schedule", PARITY_SCHEDULE)):
-            engine.set_precision_schedule(sched)
-            psteps = max(3, args.steps // 4)
-            el, _, _, outs_p = host_to_host(engine, fields, n_utt, frames, first, psteps, 1, lambda: None)
-            rfps, tmp = resident(engine, fields, min(n_utt, BLOCK), frames, first, 3)
-            outs_by_mode[name] = outs_p
-            n64, n32 = tmp["iter64_launches"], tmp["iter_launches"] - tmp["iter64_launches"]
-            t64 = tmp["dom64_ms"] / max(1, n64) * 1e-3
-            t32 = (tmp["dom_ms"] - tmp["dom64_ms"]) / max(1, n32) * 1e-3
-            precise[name] = {
-                "what": "gomel_set_precision(h, 64): k_gl_fused_d for all %d iterations" % fields["GriffinLimIterations"] if sched < 0 else
-                        "gomel_set_precision_schedule(h, %d): k_gl_fused_d for the first %d iterations, k_gl_fused (fp32) for the other %d" % (sched, sched, fields["GriffinLimIterations"] - sched),
-                "value": n_utt * frames * psteps / el, "unit": "frames/s", "steps": psteps, "ms_per_step": el / psteps * 1e3,
-                "timed_region": "the same host-to-host call as `value` (pinned fp64 buffers, H2D + all device work + D2H)",
-                "resident_frames_per_s": rfps,
-                "kernel_fp64": {"name": "k_gl_fused_d", "launches_per_call": n64 // 3, "launch_ms": t64 * 1e3,
-                                "frac_in_survey_8d_bytes": tmp["frames"] * b32 / t64 / 1e9 / HBM_PEAK_GBS if n64 else None,
-                                "frac_in_fp64_bytes": tmp["frames"] * b64 / t64 / 1e9 / HBM_PEAK_GBS if n64 else None},
-                "kernel_fp32": {"name": "k_gl_fused", "launches_per_call": n32 // 3, "launch_ms": t32 * 1e3,
-                                "frac": tmp["frames"] * b32 / t32 / 1e9 / HBM_PEAK_GBS} if n32 else None,
-            }
-
-    if rank == 0 and world == 1 and not args.no_precise:
-        guarded("precise", precise_legs)
-        guarded("precise_reset", lambda: engine.set_precision_schedule(0))
-    cpu = parity = None
-    if rank == 0 and not args.no_cpu:
+    cpu = None
+    parity_all = {}
+    if solo and not args.no_cpu:                                      # the CPU baseline is an N = 1 figure: ranks of a multi-GPU run skip it
         mode = args.parity or "sample"                                # bounded (~25 s); --parity all checks every utterance of the batch (~80 s)
         if mode != "none":
             got = guarded("cpu_baseline", lambda: cpu_legs(fields, frames, mels_last, seeds_last, outs_by_mode, mode))
             if got is not None:
                 cpu, parity_all = got
-                parity = parity_all.get("fp32")
-                for name in (precise or {}):
+                for name in modes:
                     if name in parity_all:
-                        precise[name]["parity"] = parity_all[name]
-        if world > 1:
-            cpu = None                                                # the CPU baseline is an N = 1 figure
+                        modes[name]["parity"] = parity_all[name]
+    parity = parity_all.get(args.mode)
+    # what the default call (and fp64 throughout) must show on the checked sample; the fp32 fast mode is exempt (statistical)
+    parity_ok = all(parity_all[name]["n_over_1e-4"] == 0 for name in parity_all if name != "fp32")
 
     if rank == 0:
-        N, hop, I = fields["Resolut"], fields["Window"], fields["GriffinLimIterations"]
         total_frames = world * n_utt * frames
         value = total_frames * args.steps / elapsed
-        launches = max(1, tm["iter_launches"])
-        t_launch = tm["dom_ms"] / launches * 1e-3
+        dom = max(kernels, key=lambda kname: kernels[kname]["launch_ms"] * kernels[kname]["launches_per_call"])   # the kernel a call spends most time in
+        kd = kernels[dom]
+        t_launch = kd["launch_ms"] * 1e-3
         bytes_launch = tm["frames"] * algorithmic_bytes_per_frame_iter(N, hop) * (I if tm["fast_path"] == 2 else 1)   # the persistent kernel: one launch = all I iterations
         achieved = bytes_launch / t_launch / 1e9
-        traffic, traffic_source = committed_traffic(wl if wl != "cfg5" else "cfg3", tm["fast_path"])
-        per_frame_bytes = I * algorithmic_bytes_per_frame_iter(N, hop) + fields["NumMels"] * 16 + hop * 8
+        tkey = {"k_gl_fused_d": "fused_d", "k_gl_fused": "fused", "k_gl_fused_any": "fused", "k_gl_persist": "persistent", "k_gl_frames": "generic"}.get(dom, dom)
+        traffic, traffic_source = committed_traffic(wl if wl != "cfg5" else "cfg3", tkey)
+        per_frame_bytes = I * algorithmic_bytes_per_frame_iter(N, hop) + K * 16 + hop * 8
         line = {
             "metric": "Griffin-Lim frames/s (4096-pt, 60 iters)" if N == 4096 else "Griffin-Lim frames/s (%d-pt, %d iters)" % (N, I),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc, "utterances_per_gpu": n_utt, "frames_per_utterance": frames, "resolut": N, "window_hop": hop,
-                       "num_mels": fields["NumMels"], "iterations": I, "parallelism": "utterance-sharded x%d" % world,
-                       "kernel_path": PATHS[tm["fast_path"]],
-                       "timed_region": "gomel_from_mel_batch host-to-host (pinned fp64 buffers, H2D + all device work + D2H), %d utterances per call" % min(n_utt, BLOCK)},
+                       "num_mels": K, "iterations": I, "parallelism": "utterance-sharded x%d" % world,
+                       "precision_mode": "%s: %s" % (args.mode, MODES[args.mode][1]), "fp64_iterations": engine.fp64_iterations(),
+                       "default_fp64_iterations": k_default, "kernel_path": PATHS[tm["fast_path"]],
+                       "timed_region": "gomel_from_mel_batch host-to-host (pinned fp64 buffers, H2D + all device work + D2H), %d utterances per call, %s" % (
+                           min(n_utt, BLOCK), "%d calls in flight (gomel_from_mel_batch_submit / gomel_job_wait, two sets of output buffers)" % depth if depth else
+                           "one synchronous call after the other")},
             "real_time_factor": value * hop / sr,
+            "single_caller_frames_per_s": single_caller,   # the same calls from a lone synchronous caller (the chunked gomel_from_mel_batch)
             "resident_frames_per_s": res_fps,
             "pageable_frames_per_s": pageable,
             "float32_host_io_frames_per_s": f32io,   # gomel_from_mel_batch_f32: float log-mel in, float waveforms out (half the PCIe bytes); informational
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": tm["dom_kernel"], "launch_ms": t_launch * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launch_ms": t_launch * 1e3,
                          "launch_ms_per_timed_call": tm.get("per_call_launch_ms"),
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "launch": "one launch over the whole %d-utterance batch (the configuration as BASELINE names it), HIP events on the library's stream in this process" % min(n_utt, BLOCK),
-                         "timed_region_launches": {"what": "the same kernel at the size of a full chunk of the host-to-host call (%d chunks per call, first and last half-size; copy/compute overlap)" % n_chunks,
-                                                   "frames_per_launch": tm_chunk["frames"], "launch_ms": tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]),
-                                                   "frac": tm_chunk["frames"] * algorithmic_bytes_per_frame_iter(N, hop) * (I if tm_chunk["fast_path"] == 2 else 1) /
-                                                           (tm_chunk["dom_ms"] / max(1, tm_chunk["iter_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "bytes_convention": "SURVEY 8(d): hop*4 + (N/2+1)*4 + hop*4 B per frame-iteration (fp32 device storage), for every kernel; "
+                                             "k_gl_fused_d moves twice that in its own fp64 storage (`frac_own_fp64_bytes` in `kernels`)",
+                         "launch": "one launch over the whole %d-utterance batch (the configuration as BASELINE names it; with calls in flight the timed region launches exactly this), "
+                                   "HIP events on the library's stream in this process" % min(n_utt, BLOCK),
+                         "kernels": kernels,
                          "whole_job_frac_resident": res_fps * per_frame_bytes / 1e9 / HBM_PEAK_GBS,
                          "whole_job_frac_host_to_host": value / world * per_frame_bytes / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
             "parity": parity,
-            "precise": precise,
+            "parity_assertion": {"n_over_1e-4 == 0 on the checked sample, default mode and fp64 throughout": parity_ok} if parity_all else None,
+            "modes": modes or None,
             "leg_errors": leg_errors or None,
             "single_utterance": single,
             "config1_towav_png_2_iters": cfg1,
-            "world_size": world, "backend": backend if world > 1 else None, "per_rank_frames_per_s": per_rank,
+            "world_size": world, "backend": backend if world > 1 else None,
+            "rccl_ranks": dist.get_world_size() if world > 1 and backend == "nccl" else None,
+            "per_rank": per_rank, "per_rank_frames_per_s": [r["frames_per_s"] for r in per_rank],
             "table_broadcast_s": bcast_s,
-            "device_ms": {"total": tm["total_ms"], "iterations": tm["iter_ms"], "dominant_kernel": tm["dom_ms_last_call"]},
+            "device_ms": {"total": tm["total_ms"], "iterations": tm["iter_ms"], "iteration_kernels_last_call": tm["dom_ms_last_call"]},
         }
         print(json.dumps(line), flush=True)
     engine.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_all and not parity_ok:
+        print("bench.py: PARITY ASSERTION FAILED -- an utterance of the checked sample is beyond 1e-4 in a mode that must hold it (see `parity` / `modes`)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -53,6 +53,13 @@ SYMBOLS = {
                                                 ctypes.POINTER(c_float_p), c_u64_p, ctypes.POINTER(c_float_p), c_size_p]),
     "gomel_from_mel_batch_multi": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p,
                                                   ctypes.POINTER(c_double_p), c_u64_p, ctypes.POINTER(c_double_p), c_size_p]),
+    "gomel_from_mel_batch_submit": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_double_p), c_size_p, ctypes.POINTER(c_double_p), c_u64_p,
+                                                   ctypes.POINTER(c_double_p), c_size_p, ctypes.POINTER(_vp)]),
+    "gomel_from_mel_batch_submit_f32": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_float_p), c_size_p, ctypes.POINTER(c_float_p), c_u64_p,
+                                                       ctypes.POINTER(c_float_p), c_size_p, ctypes.POINTER(_vp)]),
+    "gomel_job_wait": (ctypes.c_int, [_vp]),
+    "gomel_set_call_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "gomel_job_poll": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     "gomel_plan_chunks": (ctypes.c_int, [_cfg_p, ctypes.c_size_t, c_size_p, c_size_p, ctypes.c_size_t, c_size_p]),
     "gomel_host_alloc": (_vp, [ctypes.c_size_t]),
     "gomel_host_free": (ctypes.c_int, [_vp]),
@@ -74,6 +81,8 @@ SYMBOLS = {
     "gomel_set_path": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_set_precision": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_set_precision_schedule": (ctypes.c_int, [_vp, ctypes.c_int32]),
+    "gomel_auto_fp64_iterations": (ctypes.c_int32, [_cfg_p, ctypes.c_int32]),
+    "gomel_get_precision": (ctypes.c_int, [_vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     "gomel_to_mel_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_size_t]),
     "gomel_to_mel": (ctypes.c_int, [_vp, c_double_p, ctypes.c_size_t, c_double_p, ctypes.c_size_t, c_size_p]),
     "gomel_phase_pairs": (ctypes.c_size_t, [_cfg_p, ctypes.c_int32, ctypes.c_size_t]),
@@ -91,6 +100,8 @@ SYMBOLS = {
     "gomel_device_count": (ctypes.c_int, []),
     "gomel_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
 }
+
+SCHEDULE_AUTO = -2 ** 31      # GOMEL_SCHEDULE_AUTO
 
 _lib = None
 

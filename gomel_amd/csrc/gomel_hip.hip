@@ -48,6 +48,8 @@ struct DeviceGuard {
     } catch (const std::bad_alloc&) { return GOMEL_ERR_NO_MEMORY; } \
     catch (...) { return GOMEL_ERR_NO_MEMORY; }
 
+enum { kPrecAuto = 0, kPrecFp32 = 32, kPrecFp64 = 64, kPrecSchedule = 1 };
+
 struct TableHeader {
     uint32_t magic, version;
     int32_t n, hop, k, hann_periodic;
@@ -107,9 +109,14 @@ struct gomel_handle {
     hipStream_t copy_stream = nullptr;  // D2H of finished chunks, overlapped with the next chunk's compute
     hipStream_t up_stream = nullptr;    // H2D of the next chunk, overlapped with this chunk's compute
     std::mutex mu;
+    std::atomic<int> call_mode{0};         // gomel_set_call_mode: 0 = a synchronous batch call is chunked, 1 = it is one whole batch (submit + wait)
     int path_mode = 0;
-    int precision = 32;           // 32: fp32 kernels (default); 64: fp64 generic kernels ("precise" mode)
-    int precise_iters = -1;       // 64-bit mode only: >= 0 = run that many iterations in fp64 and the rest in fp32 (gomel_set_precision_schedule); -1 = all of them
+    // Arithmetic of the Griffin-Lim iterations (gomel_set_precision / gomel_set_precision_schedule): kPrecAuto (default) = the
+    // calibrated schedule gomel_auto_fp64_iterations(cfg, I) -- what a caller gets without a knob agrees with the reference's float64
+    // arithmetic within 1e-4 RMS; kPrecFp32 = fp32 kernels throughout (the opt-in fast mode); kPrecFp64 = fp64 throughout;
+    // kPrecSchedule = the first precise_iters iterations in fp64, the rest in fp32.
+    int precision = kPrecAuto;
+    int precise_iters = -1;       // kPrecSchedule: iterations in fp64 before the fp32 kernels take over
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
     bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
     // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
@@ -209,6 +216,41 @@ static int validate_config(const gomel_config* c) {
     if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
     if (!gomel_supported_n(c->resolut) && !gomel_generic_n(c->resolut)) return GOMEL_ERR_UNSUPPORTED_N;
     return GOMEL_OK;
+}
+
+// The automatic precision schedule: how many of a call's I Griffin-Lim iterations run in fp64 before the fp32 kernels take over.
+// CALIBRATED on the GPU (scripts/calibrate_schedule.py, profiles/r04/calibration/): for every I below and the three geometries
+// towav (N 4096 / hop 1280), TTS (1024 / 256) and NewMel's defaults (2048 / 256), 4096 iid-random and 4096 signal-derived
+// utterances of 400 frames each; the entry is the smallest k tried for which NO utterance of any of the six sets ended more than
+// 3e-5 RMS from fp64 throughout (a 3x margin under the 1e-4 bar of SURVEY 8(b): the error distribution is heavy-tailed, DESIGN.md
+// section 2).  What the data show (24 576 utterances per schedule): the iteration is most unstable in its FIRST iterations, from the
+// random initial signal (mel/mel.go:80-83) -- fp32 throughout leaves 1.1 % of 60-iteration utterances beyond 1e-4, ten fp64 iterations
+// first 0.1 %, 35 none of the 24 576 -- but the tail never closes: single utterances amplify the rounding of the LAST fifteen iterations
+// a thousandfold (one of 24 576 beyond 1e-4 at k = 45 of 60), so a schedule bounds the RATE of such utterances, about 1 in 10^4 to 10^5
+// at these entries; only fp64 throughout excludes them.  Even two fp32 iterations leave 2 of 24 576 beyond 3e-5, hence k(2) = 1.
+// Between calibrated points k is interpolated upwards; beyond the last one the number of trailing fp32 iterations is held at its 20.
+struct AutoPoint { int iters, k; };
+static const AutoPoint kAutoSchedule[] = {{2, 1}, {5, 3}, {10, 6}, {20, 10}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};   // profiles/r04/calibration/TABLE.txt
+static int auto_fp64_iterations(int I) {
+    constexpr int n = (int)(sizeof kAutoSchedule / sizeof kAutoSchedule[0]);
+    if (I <= kAutoSchedule[0].iters) return std::min(I, kAutoSchedule[0].k);
+    for (int i = 1; i < n; i++)
+        if (I <= kAutoSchedule[i].iters) {
+            const AutoPoint a = kAutoSchedule[i - 1], b = kAutoSchedule[i];
+            const int k = a.k + ((b.k - a.k) * (I - a.iters) + (b.iters - a.iters) - 1) / (b.iters - a.iters);   // rounded up
+            return std::min(I, std::max(k, a.k));
+        }
+    return I - (kAutoSchedule[n - 1].iters - kAutoSchedule[n - 1].k);
+}
+// fp64 iterations of a call of I iterations on this handle: 0 = fp32 throughout, >= I = fp64 throughout.  Caller holds h->mu.
+static int resolve_fp64_iterations(const gomel_handle* h, int I) {
+    if (h->generic) return I;                              // the generic-length kernels are fp64
+    switch (h->precision) {
+        case kPrecFp32: return 0;
+        case kPrecFp64: return I;
+        case kPrecSchedule: return std::min(I, std::max(0, h->precise_iters));
+        default: return auto_fp64_iterations(I);
+    }
 }
 
 template <class V> static void fill_twiddles(int N, int R1, int R2, std::vector<V>& tw1, std::vector<V>& tw2, std::vector<V>& wn) {
@@ -380,6 +422,9 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         memset(h->err_slab, 0, kErrSlots * sizeof(unsigned));
         for (int i = kErrSlots - 1; i >= 0; i--) h->err_free.push_back(i);
     } else { h->err_slab = nullptr; (void)hipGetLastError(); }   // no slab: the persistent path is simply never chosen
+    // GOMEL_PRECISION = auto | 32 | 64: the mode a handle STARTS in (default auto), for deployments that choose the fast mode -- or
+    // fp64 throughout -- without touching the host program; gomel_set_precision / gomel_set_precision_schedule override it
+    if (const char* e = getenv("GOMEL_PRECISION")) h->precision = !strcmp(e, "32") ? kPrecFp32 : !strcmp(e, "64") ? kPrecFp64 : kPrecAuto;
     if (const char* e = getenv("GOMEL_PERSIST_TICKS")) h->persist_ticks = (unsigned)strtoul(e, nullptr, 10);
     if (const char* e = getenv("GOMEL_PERSIST_NAP")) h->persist_nap = atoi(e);
     rc = upload_tables(h);
@@ -522,6 +567,7 @@ struct gomel_batch {
     int n_wg = 0;
     int err_slot = -1;
     int persist_units = 0;     // share of the device this batch's queued persistent launch is accounted with (persist_take)
+    hipEvent_t gate_ev = nullptr;   // recorded behind every run of this batch: how the device gate sees its work finish
     int32_t* d_frame_utt = nullptr;
     unsigned* d_ctl = nullptr;
     size_t ctl_bytes = 0;
@@ -531,9 +577,12 @@ struct gomel_batch {
 static inline size_t istft_row(int N) { return (size_t)(N / 2 + 1 + (N & 1)); }
 static inline hipStream_t run_stream(const gomel_batch* b) { return b->rs ? b->rs : b->h->stream; }
 static void persist_release(gomel_batch* b);
+static void gate_forget(gomel_batch* b);
 static void batch_free(gomel_batch* b) {
     if (!b) return;
     DeviceGuard dg(b->h->device);
+    gate_forget(b);
+    if (b->gate_ev) hipEventDestroy(b->gate_ev);
     void* ptrs[] = {b->d_spec, b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
                     b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_midd, b->d_xd[0], b->d_xd[1], b->d_ywd,
                     b->d_frame_utt, b->d_ctl};
@@ -765,25 +814,107 @@ template <int N> static void launch_frames(gomel_batch* b, const float* x) {
 
 static int batch_run_impl(gomel_batch* b, gomel_timing* tm);
 
-// Persistent launches of DIFFERENT handles on one device must not overlap beyond the chip's capacity: each needs all its
-// workgroups resident, and two half-resident launches would wait for each other until both give up.  Launches are therefore
-// accounted in 1/1024ths of the device (n_wg against the census of the build in use) from the moment they are queued until the
-// host has seen them finish (sync / download / destroy); a run that finds no room goes through the per-iteration kernels instead
-// (same bits).  Within one process only: another process on the same GPU is what the kernel's own time limit is for.
-static std::atomic<int> g_persist_units[64];
+// THE DEVICE GATE.  A persistent launch (k_gl_persist) needs every one of its workgroups resident at once -- a 512-register workgroup
+// wants a whole SIMD to itself -- and waits inside the launch for its neighbours.  Two things of THIS process can keep it from that
+// (another process on the same GPU is what the kernel's own time limit is for):
+//   * other persistent launches: two half-resident ones would wait for each other until both give up.  Launches are accounted in
+//     1/1024ths of the device (n_wg against the census of the build in use) from the moment they are queued until the host has seen
+//     them finish (sync / download / destroy); a run that finds no room goes through the per-iteration kernels (same bits);
+//   * ordinary kernels of other handles (per-iteration kernels, fused batches, ToMel): a stream of them from three threads kept one
+//     workgroup of a persistent launch from its SIMD beyond the 20 ms spin limit in round 3 (tests/test_gpu_persist.py, the
+//     four-handle test).  So a batch takes the persistent path only while NO other kernel work of this process is in flight on the
+//     device -- counted from the moment its enqueueing begins until the event recorded behind it has completed -- and whatever is
+//     enqueued while persistent launches are in flight first makes its stream wait for them (hipStreamWaitEvent: <= 0.6 ms of
+//     device-side ordering, nothing blocks on the host).  The gate's mutex is held while a persistent launch is being enqueued
+//     (~0.1 ms), so that "nothing else in flight" still holds when its kernel reaches the queue.
+struct DeviceGate {
+    struct Ent { hipEvent_t ev; const gomel_batch* owner; };
+    std::mutex mu;
+    int persist_units = 0;      // 1/1024ths of the device taken by queued persistent launches
+    int enqueueing = 0;         // ordinary runs that have entered the gate and not yet recorded their event
+    std::vector<Ent> np;        // events behind ordinary kernel work in flight
+    std::vector<Ent> ps;        // events behind persistent launches in flight
+    static void prune(std::vector<Ent>& v) {   // caller holds mu; drops what has completed
+        size_t k = 0;
+        for (size_t i = 0; i < v.size(); i++) {
+            const hipError_t e = hipEventQuery(v[i].ev);
+            if (e == hipErrorNotReady) v[k++] = v[i];
+            else if (e != hipSuccess) (void)hipGetLastError();
+        }
+        v.resize(k);
+    }
+    static void put(std::vector<Ent>& v, hipEvent_t ev, const gomel_batch* owner) {
+        for (const Ent& e : v) if (e.ev == ev) return;   // re-recorded: the entry now stands for the latest record
+        v.push_back(Ent{ev, owner});
+    }
+};
+static DeviceGate g_gate[64];
+static inline DeviceGate& gate_of(const gomel_handle* h) { return g_gate[h->device & 63]; }
+
+// Ordinary (non-persistent) kernel work on `s`: enter before the first launch, leave behind the last one.  leave(ev): ev has just been
+// recorded behind the work; leave(nullptr): the work has been synchronised with, nothing stays in flight.
+struct GateOrdinary {
+    DeviceGate* g = nullptr;
+    void enter(const gomel_handle* h, hipStream_t s) {
+        g = &gate_of(h);
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->enqueueing++;
+        DeviceGate::prune(g->ps);
+        for (const DeviceGate::Ent& e : g->ps) if (hipStreamWaitEvent(s, e.ev, 0) != hipSuccess) (void)hipGetLastError();
+    }
+    void leave(hipEvent_t ev, const gomel_batch* owner) {
+        if (!g) return;
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->enqueueing--;
+        if (ev) DeviceGate::put(g->np, ev, owner);
+        g = nullptr;
+    }
+    ~GateOrdinary() { leave(nullptr, nullptr); }   // an early error return: whatever was queued is drained by the caller's error path
+};
+
 static int persist_units(gomel_batch* b) {
     const int census = std::max(1, persist_census(b->h, b->persist));
     return (int)std::min<int64_t>(1024, ((int64_t)b->n_wg * 1024 + census - 1) / census);
 }
-static bool persist_take(gomel_batch* b) {   // caller holds h->mu and a DeviceGuard
-    if (b->persist_units) return true;        // an earlier run of this batch is still accounted: same stream, it runs behind it
-    const int u = persist_units(b), dev = b->h->device & 63;
-    if (g_persist_units[dev].fetch_add(u) + u > 1024) { g_persist_units[dev].fetch_sub(u); return false; }
-    b->persist_units = u;
-    return true;
-}
+// A persistent run: takes the gate (and keeps its mutex) when the device is free of other work and has room; `locked` then stays set
+// until leave() has recorded the launch.  Caller holds h->mu and a DeviceGuard.
+struct GatePersist {
+    DeviceGate* g = nullptr;
+    bool locked = false;
+    bool take(gomel_batch* b) {
+        g = &gate_of(b->h);
+        g->mu.lock();
+        DeviceGate::prune(g->np);
+        bool others = g->enqueueing != 0;
+        for (const DeviceGate::Ent& e : g->np) others |= e.owner != b;   // (its own earlier runs sit on the same stream: it runs behind them)
+        const int u = b->persist_units ? 0 : persist_units(b);            // an earlier run of this batch still accounted: same stream, same share
+        if (others || g->persist_units + u > 1024) { g->mu.unlock(); g = nullptr; return false; }
+        g->persist_units += u;
+        if (u) b->persist_units = u;
+        locked = true;
+        return true;
+    }
+    void leave(gomel_batch* b, hipEvent_t ev) {   // ev recorded behind the launch (null: nothing was launched after all)
+        if (!locked) return;
+        if (ev) DeviceGate::put(g->ps, ev, b);
+        locked = false;
+        g->mu.unlock();
+    }
+    ~GatePersist() { if (locked) { locked = false; g->mu.unlock(); } }
+};
 static void persist_release(gomel_batch* b) {   // the batch's launches are known to have finished (or never ran)
-    if (b->persist_units) { g_persist_units[b->h->device & 63].fetch_sub(b->persist_units); b->persist_units = 0; }
+    if (!b->persist_units) return;
+    DeviceGate& g = gate_of(b->h);
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.persist_units -= b->persist_units;
+    b->persist_units = 0;
+    for (size_t i = 0; i < g.ps.size();) { if (g.ps[i].owner == b) g.ps.erase(g.ps.begin() + i); else i++; }
+}
+static void gate_forget(gomel_batch* b) {       // the batch (and its event) is going away
+    DeviceGate& g = gate_of(b->h);
+    std::lock_guard<std::mutex> lk(g.mu);
+    for (std::vector<DeviceGate::Ent>* v : {&g.np, &g.ps})
+        for (size_t i = 0; i < v->size();) { if ((*v)[i].owner == b) v->erase(v->begin() + i); else i++; }
 }
 
 // A persistent launch gave up (k_gl_persist: a workgroup waited 20 ms for a neighbour -- some other context held the CUs it
@@ -814,8 +945,12 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     const int N = c.resolut, K = c.num_mels, I = b->iters >= 0 ? b->iters : c.griffin_lim_iterations;
     hipStream_t s = run_stream(b);
     if (!b->uploaded) return GOMEL_ERR_NULL;
-    // this run's path: the batch's persistent kernel only while the chip has room for it next to the other handles' (persist_take)
-    const int persist = (b->persist && I > 0 && persist_take(b)) ? b->persist : 0;
+    // this run's path: the batch's persistent kernel only while the device is free of this process's other work and has room for it
+    // next to the other handles' persistent launches (the device gate); everything else waits for persistent launches in flight
+    GatePersist gate_p;
+    GateOrdinary gate_o;
+    const int persist = (b->persist && I > 0 && gate_p.take(b)) ? b->persist : 0;
+    if (!persist) gate_o.enter(h, s);
     if (tm) {
         while ((int)b->dom_ev.size() < 2 * I) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->dom_ev.push_back(e); }
         HIPCHK(hipEventRecord(b->ev[0], s));
@@ -837,12 +972,16 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 else hipLaunchKernelGGL(k_mel_to_mag_nat<double>, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
             }
             else if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
+            else if (b->io32) HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel32, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
             else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
-            if (b->io32) hipLaunchKernelGGL((k_init_x<double, float>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x032, b->d_xd[0]);   // (generic lengths with float host buffers)
+            if (b->io32) hipLaunchKernelGGL((k_init_x<double, float>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x032, b->d_xd[0]);   // float host buffers
             else hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
-            if (b->mixed_k) {   // the fp32 kernel's magnitudes: the same fp64 values, rounded once
-                if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
-                else HIPCHK(launch_mel_to_mag<float>(N, b->total_frames, s, mel64, h->dt.undo, b->d_mag, b->d_nyq, K, c.tune_add, c.tune_mul));
+            if (b->mixed_k) {
+                // the fp32 kernel's magnitudes: the same fp64 values rounded once -- k_mel_to_mag<float> computes in fp64 and rounds on
+                // the store, in the same lane-slot order, so narrowing the fp64 rows gives its very bits at a third of its time
+                const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
             }
             if (tm) HIPCHK(hipEventRecord(b->ev[1], s));
             int curd = 0;
@@ -872,8 +1011,13 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 }
                 if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
                 const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
-                hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
-                if (b->fast == 1) hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
+                if (b->io32) {
+                    hipLaunchKernelGGL(k_finalize<float>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out32, b->total_len);
+                    if (b->fast == 1) hipLaunchKernelGGL(k_add_tails<float>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out32, N - c.window, c.window);
+                } else {
+                    hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
+                    if (b->fast == 1) hipLaunchKernelGGL(k_add_tails<double>, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_tail[cur], out64, N - c.window, c.window);
+                }
             } else {
             if (persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
                 const size_t buf_doubles = (size_t)b->total_frames * N;
@@ -883,7 +1027,9 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
                                                        b->d_ywd, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
-                hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd + (size_t)((I - 1) % 3) * buf_doubles, out64, N, c.window);
+                // x_I = the overlap-add of the last iteration's frames (float host buffers: summed in fp64 into the idle second signal buffer, narrowed below)
+                hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd + (size_t)((I - 1) % 3) * buf_doubles, b->io32 ? b->d_xd[1] : out64, N, c.window);
+                if (b->io32) hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[1], out32, b->total_len);
             }
             for (int it = 0; it < I && !persist; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
@@ -903,9 +1049,10 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                                    b->d_xd[curd ^ 1], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_spec, b->total_frames, N, h->dt.windowd, h->dt.any, b->d_midd);
             else if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_spec_writeback<NN, v2d>), dim3((unsigned)blocks), dim3(128), 0, s, b->d_xd[curd ^ 1], b->d_frame_xoff, mel64, b->d_spec, b->total_frames, h->dt));
+            // the fused kernel's tails are folded into x in place, in fp64 (the any-hop form folds its tails itself), then x leaves in the caller's type
+            if (b->fast == 1) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], b->d_xd[curd], N - c.window, c.window);
             if (!persist && b->io32) hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[curd], out32, b->total_len);
             else if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
-            if (b->fast == 1) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], out64, N - c.window, c.window);   // (the any-hop form folds its tails itself)
             }   // !mixed_k
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
@@ -963,6 +1110,9 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
     }
     if (persist && I > 0) HIPCHK(hipMemcpyAsync(h->err_slab + b->err_slot, b->d_ctl, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->gate_ev, s));
+    gate_p.leave(b, b->gate_ev);
+    gate_o.leave(b->gate_ev, b);
     if (tm) {
         HIPCHK(hipEventRecord(b->ev[3], s));
         HIPCHK(hipEventSynchronize(b->ev[3]));
@@ -1001,6 +1151,7 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     if (n_frames == 0) return GOMEL_ERR_EMPTY;
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
+    GateOrdinary gate_o; gate_o.enter(h, h->stream);   // synchronous entry point: the gate is left (destructor) after its streams have drained
     const int N = h->cfg.resolut;
     const size_t in_b = n_frames * (inverse ? (size_t)(N + 2) : (size_t)N) * 4, out_b = n_frames * (inverse ? (size_t)N : (size_t)(N + 2)) * 4;
     float *d_in = nullptr, *d_out = nullptr;
@@ -1135,19 +1286,39 @@ int gomel_set_path(gomel_handle* h, int mode) {
     return GOMEL_OK;
 }
 
+int gomel_set_call_mode(gomel_handle* h, int mode) {
+    if (!h) return GOMEL_ERR_NULL;
+    if (mode != 0 && mode != 1) return GOMEL_ERR_BAD_CONFIG;
+    h->call_mode.store(mode);
+    return GOMEL_OK;
+}
 int gomel_set_precision(gomel_handle* h, int bits) {
     if (!h) return GOMEL_ERR_NULL;
-    if (bits != 32 && bits != 64) return GOMEL_ERR_BAD_CONFIG;
+    if (bits != 0 && bits != 32 && bits != 64) return GOMEL_ERR_BAD_CONFIG;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->precision = bits;
+    h->precision = bits == 0 ? kPrecAuto : bits == 32 ? kPrecFp32 : kPrecFp64;
     h->precise_iters = -1;
     return GOMEL_OK;
 }
 int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations) {
     if (!h) return GOMEL_ERR_NULL;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->precision = fp64_iterations == 0 ? 32 : 64;
-    h->precise_iters = fp64_iterations > 0 ? fp64_iterations : -1;
+    if (fp64_iterations == GOMEL_SCHEDULE_AUTO) { h->precision = kPrecAuto; h->precise_iters = -1; }
+    else if (fp64_iterations == 0) { h->precision = kPrecFp32; h->precise_iters = -1; }
+    else if (fp64_iterations < 0) { h->precision = kPrecFp64; h->precise_iters = -1; }
+    else { h->precision = kPrecSchedule; h->precise_iters = fp64_iterations; }
+    return GOMEL_OK;
+}
+int32_t gomel_auto_fp64_iterations(const gomel_config* cfg, int32_t iterations) {
+    if (!cfg || iterations <= 0) return 0;
+    if (!gomel_supported_n(cfg->resolut)) return iterations;   // generic-length kernels: fp64
+    return auto_fp64_iterations(iterations);
+}
+int gomel_get_precision(const gomel_handle* h, int32_t iterations, int32_t* fp64_iterations) {
+    if (!h || !fp64_iterations) return GOMEL_ERR_NULL;
+    if (iterations < 0) iterations = h->cfg.griffin_lim_iterations;
+    std::lock_guard<std::mutex> lk(const_cast<gomel_handle*>(h)->mu);
+    *fp64_iterations = resolve_fp64_iterations(h, iterations);
     return GOMEL_OK;
 }
 
@@ -1221,7 +1392,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     b->h = h; b->n_utt = n_utt; b->direct = direct; b->iters = iters;
     h->batches_seen++;
     b->io32 = (flags & BF_IO32) ? 1 : 0; b->esz = b->io32 ? 4 : 8; b->want_spec = (flags & BF_SPEC) ? 1 : 0;
-    if (b->io32 && (direct || h->precision == 64)) return GOMEL_ERR_BAD_CONFIG;   // fp32 host I/O: log-mel entry points, fp32 kernels
+    if (b->io32 && direct) return GOMEL_ERR_BAD_CONFIG;   // fp32 host I/O: the log-mel entry points (any precision mode: float at the boundary, the mode's arithmetic inside)
     b->utts.resize(n_utt); b->n_pairs.assign(n_pairs, n_pairs + n_utt);
     for (size_t u = 0; u < n_utt; u++) {
         UttDesc& d = b->utts[u];
@@ -1236,8 +1407,9 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // every iteration in one launch, ~9 us per iteration whatever the frame count.  Beyond that the fused kernel, which walks
     // consecutive frames per stream and so only pays once there are enough frames to fill the chip (fused_min_frames); in
     // between (and for hops neither takes) every frame in parallel, two launches per iteration (generic kernels).
-    b->precise = (h->precision == 64 || h->generic) ? 1 : 0;   // the generic-length kernels are fp64
     const int I = iters >= 0 ? iters : c.griffin_lim_iterations;
+    const int k64 = resolve_fp64_iterations(h, I);            // fp64 iterations of this call (0: fp32 throughout; I: fp64 throughout)
+    b->precise = (k64 > 0 || h->generic) ? 1 : 0;
     // (every frame gathers its whole window from the covering frames, N/hop times the bytes of k_ola's single pass: beyond eight
     // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms
     // generic, hop 128 1.25 against 1.14 -- so the library picks the kernel down to hop = N/8 only; gomel_set_path(h, 3) still runs it)
@@ -1263,7 +1435,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     // Precision schedule: only where it pays -- the fused kernel's batches.  Everything smaller (persistent / generic kernels: a
     // handful of utterances) and the generic lengths stay fp64 for the whole call: correct, and cheap at that size.
-    if (b->precise && !h->generic && b->fast && h->precise_iters > 0 && h->precise_iters < I) b->mixed_k = h->precise_iters;
+    if (b->precise && !h->generic && b->fast && k64 > 0 && k64 < I) b->mixed_k = k64;
     int rc = GOMEL_OK;
     const hipStream_t ist = init_stream ? init_stream : h->stream;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
@@ -1274,7 +1446,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     alloc((void**)&b->d_utts, n_utt * sizeof(UttDesc));
     if (I > 0 && b->precise) {
         alloc((void**)&b->d_magd, (size_t)b->total_frames * (N / 2) * 8);
-        alloc((void**)&b->d_nyqd, (size_t)b->total_frames * 8);
+        alloc((void**)&b->d_nyqd, ((size_t)b->total_frames + 4) * 8);   // + 4: narrowed four at a time into d_nyq (precision schedule)
         alloc((void**)&b->d_xd[0], (size_t)b->total_len * 8);
         alloc((void**)&b->d_xd[1], (size_t)b->total_len * 8);
         if (b->fast) {   // fp64 fused kernel: segments and tails as in the fp32 case, no per-frame output buffer
@@ -1327,6 +1499,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         }
     }
     for (auto& e : b->ev) if (!rc && hipEventCreate(&e) != hipSuccess) rc = GOMEL_ERR_HIP;
+    if (!rc && hipEventCreateWithFlags(&b->gate_ev, hipEventDisableTiming) != hipSuccess) rc = GOMEL_ERR_HIP;
     // (the per-frame index tables d_frame_xoff / d_frame_utt are filled on the device, behind the utterance descriptors: batch_upload_impl)
     if (rc) return rc;
     guard.b = nullptr;
@@ -1514,7 +1687,7 @@ static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, co
 // streams: chunk c+1's log-mel goes up (up_stream) while chunk c computes (stream) and chunk c-1's waveforms come down
 // (copy_stream); PCIe is full duplex, so with pinned host buffers the wall time is the compute time plus the first upload and
 // the last download.  Caller buffers that are not already pinned (gomel_host_alloc / gomel_host_register) are pinned for the call.
-static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
+static int from_mel_batch_chunked(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
                                   const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
     if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
@@ -1633,6 +1806,125 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
     return rc;
 }
 
+// ----------------------------------------------------------------------------------------------- jobs: calls in flight
+// A chunked call hides its copies behind its own kernels, but pays for that with chunk-sized launches (12 800 frames where the
+// whole batch has 102 400: 0.365 instead of 0.40 of the HBM roofline) and still exposes its first upload and last download.  With
+// MORE THAN ONE call in flight none of that is needed: every call is ONE whole batch -- upload on the upload stream, all its
+// kernels in whole-batch launches on the compute stream, download on the copy stream -- and the copies of call n+1 / n-1 run
+// beside the kernels of call n.  gomel_from_mel_batch_submit queues a call like that and returns; gomel_job_wait blocks until its
+// waveforms are in the caller's buffers.  Two synchronous gomel_from_mel_batch calls that overlap on one handle (two goroutines)
+// on a handle in whole-batch call mode (gomel_set_call_mode) are run the same way.
+struct gomel_job {
+    gomel_handle* h = nullptr;
+    gomel_batch* b = nullptr;
+    PinnedScope pins;                 // the caller's buffers stay pinned until the job has been waited for
+    hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+    int status = GOMEL_OK;            // of a job that ran to completion inside submit (a batch too small for the fused kernels)
+    bool completed = false;
+};
+
+static void job_drop(gomel_job* j) {  // caller has made sure nothing of the job is still in flight
+    if (j->b) { std::lock_guard<std::mutex> lk(j->h->mu); batch_free(j->b); j->b = nullptr; }
+    for (hipEvent_t e : {j->up, j->done, j->down}) if (e) hipEventDestroy(e);
+    delete j;                         // releases the pins (no stream is drained: the caller has done what was needed)
+}
+
+static bool whole_batch_pays(const gomel_handle* h, size_t n_utt, const size_t* n_pairs) {
+    if (!fused_applicable(h->cfg) || h->path_mode == 1 || h->path_mode == 3) return false;
+    int64_t frames = 0;
+    for (size_t u = 0; u < n_utt; u++) frames += (int64_t)(n_pairs[u] / (size_t)h->cfg.num_mels);
+    return frames >= 2 * fused_min_frames(h->cfg);   // below that a call is a handful of launches: nothing to pipeline
+}
+
+static int submit_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
+                          const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32, gomel_job** job_out) {
+    if (!h || !mel || !n_pairs || !out || !job_out) return GOMEL_ERR_NULL;
+    *job_out = nullptr;
+    if (n_utt == 0) return GOMEL_ERR_EMPTY;
+    const int K = h->cfg.num_mels;
+    const size_t esz = io32 ? 4 : 8;
+    for (size_t u = 0; u < n_utt; u++) {
+        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
+        if (n_pairs[u] % (size_t)K) return GOMEL_ERR_BAD_LENGTH;
+        if (!mel[u] || !out[u]) return GOMEL_ERR_NULL;
+        if (out_cap && out_cap[u] < gomel_out_len(&h->cfg, n_pairs[u])) return GOMEL_ERR_BUFFER_TOO_SMALL;
+    }
+    gomel_job* j = new (std::nothrow) gomel_job();
+    if (!j) return GOMEL_ERR_NO_MEMORY;
+    j->h = h;
+    if (!whole_batch_pays(h, n_utt, n_pairs)) {   // small: run it now, hand back a finished job
+        j->status = from_mel_batch_chunked(h, n_utt, mel, n_pairs, x0, seeds, out, out_cap, io32);
+        j->completed = true;
+        *job_out = j;
+        return GOMEL_OK;
+    }
+    int rc = batch_create_common(h, n_utt, n_pairs, io32 ? BF_IO32 : 0, -1, &j->b, h->up_stream);
+    if (!rc && j->b->persist) rc = GOMEL_ERR_BAD_CONFIG;   // (cannot happen above the fused threshold; a persistent launch wants a verifying wait)
+    bool queued = false;
+    if (!rc) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        DeviceGuard dg(h->device);
+        if (dg.err != hipSuccess) rc = GOMEL_ERR_HIP;
+        gomel_batch* b = j->b;
+        b->rs = h->stream;
+        for (size_t u = 0; u < n_utt && !rc; u++) {
+            j->pins.want(mel[u], n_pairs[u] * 2 * esz);
+            j->pins.want(out[u], (size_t)b->utts[u].len * esz);
+            if (x0 && x0[u]) j->pins.want(x0[u], (size_t)b->utts[u].len * esz);
+        }
+        if (!rc) j->pins.commit();   // no stream to drain at release: gomel_job_wait has seen the job's last copy finish
+        for (hipEvent_t* e : {&j->up, &j->done, &j->down})
+            if (!rc && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = GOMEL_ERR_HIP;
+        if (!rc) { queued = true; rc = batch_upload_impl(b, mel, x0, seeds, false, false, h->up_stream); }   // default seeds: the utterance index within the call
+        if (!rc && (hipEventRecord(j->up, h->up_stream) != hipSuccess || hipStreamWaitEvent(h->stream, j->up, 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+        if (!rc) rc = batch_run_impl(b, nullptr);
+        if (!rc && (hipEventRecord(j->done, h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, j->done, 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
+        for (size_t u = 0; u < n_utt && !rc; u++)
+            if (hipMemcpyAsync(out[u], (char*)b->d_out + (size_t)b->utts[u].xoff * esz, (size_t)b->utts[u].len * esz, hipMemcpyDefault, h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+        if (!rc && hipEventRecord(j->down, h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
+        if (rc == GOMEL_ERR_HIP) g_last_hip = (int)hipGetLastError();
+        if (rc && queued) {   // something of this job may be in flight: drain before its buffers and pins go
+            (void)hipStreamSynchronize(h->up_stream); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->copy_stream);
+            (void)hipGetLastError();
+        }
+    }
+    if (rc) { job_drop(j); return rc; }
+    *job_out = j;
+    return GOMEL_OK;
+}
+
+static int job_wait_guarded(gomel_job* j) {
+    if (!j) return GOMEL_ERR_NULL;
+    int rc = j->status;
+    if (!j->completed) {
+        DeviceGuard dg(j->h->device);
+        if (dg.err != hipSuccess || hipEventSynchronize(j->down) != hipSuccess) {
+            g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
+            (void)hipStreamSynchronize(j->h->up_stream); (void)hipStreamSynchronize(j->h->stream); (void)hipStreamSynchronize(j->h->copy_stream);
+            (void)hipGetLastError();
+        }
+    }
+    job_drop(j);
+    return rc;
+}
+
+// The synchronous call.  By default it is cut into chunks that hide their copies behind each other's kernels: the best a LONE caller
+// can get.  A host that overlaps calls on one handle (two goroutines calling in a loop) switches the handle to whole-batch calls
+// (gomel_set_call_mode(h, 1)): every call is then one submit + wait, and the copies of one call run beside the whole-batch kernels
+// of the other.  The mode is the caller's choice, never guessed from what happens to be in flight: the two modes cut an utterance
+// into different segments (other summation order of the overlap-add), so their results differ at rounding level, and what a call
+// returns must not depend on timing.
+static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
+                                  const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
+    if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
+    if (h->call_mode.load() == 1) {
+        gomel_job* j = nullptr;
+        const int rc = submit_guarded(h, n_utt, mel, n_pairs, x0, seeds, out, out_cap, io32, &j);   // (a small call runs chunked inside)
+        return rc ? rc : job_wait_guarded(j);
+    }
+    return from_mel_batch_chunked(h, n_utt, mel, n_pairs, x0, seeds, out, out_cap, io32);
+}
+
 // One call, several GPUs: contiguous utterance shards balanced by frame count, one host thread per handle (a handle = one
 // device), no data-path collective.  What a Go host uses to drive the 8 GPUs of a node without Python; every
 // handle must have been created from the same configuration (use gomel_create_from_tables for bit-identical tables).
@@ -1744,6 +2036,7 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
     const size_t F = n_pairs / (size_t)K;  // (rows come back in lane-slot order and are un-permuted below)
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
+    GateOrdinary gate_o; gate_o.enter(h, h->stream);   // synchronous entry point: the gate is left (destructor) after its streams have drained
     double* d_mel = nullptr; float *d_mag = nullptr, *d_nyq = nullptr;
     int rc = GOMEL_OK;
     if (h->pool.alloc((void**)&d_mel, n_pairs * 16) != hipSuccess || h->pool.alloc((void**)&d_mag, F * H * 4) != hipSuccess ||
@@ -1807,6 +2100,7 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
         for (size_t f = 0; f < F[u]; f++) fx[foff[u] + f] = (int64_t)(woff[u] + f * (size_t)hop);
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
+    GateOrdinary gate_o; gate_o.enter(h, h->stream);   // synchronous entry point: the gate is left (destructor) after its streams have drained
     double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
     int64_t* d_fx = nullptr;
     int rc = GOMEL_OK;
@@ -1907,6 +2201,7 @@ static int to_phase_guarded(gomel_handle* h, int32_t num_freqs, const double* wa
     if (cap_pairs < pairs) return GOMEL_ERR_BUFFER_TOO_SMALL;
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
+    GateOrdinary gate_o; gate_o.enter(h, h->stream);   // synchronous entry point: the gate is left (destructor) after its streams have drained
     double *d_wave = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;
@@ -1949,6 +2244,7 @@ static int from_phase_guarded(gomel_handle* h, int32_t num_freqs, double volume_
     }
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard dg(h->device); HIPCHK(dg.err);
+    GateOrdinary gate_o; gate_o.enter(h, h->stream);   // synchronous entry point: the gate is left (destructor) after its streams have drained
     double *d_in = nullptr, *d_yw = nullptr, *d_out = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;
@@ -2084,6 +2380,27 @@ int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel
 int gomel_from_mel_batch_f32(gomel_handle* h, size_t n_utt, const float* const* mel, const size_t* n_pairs, const float* const* x0,
                              const uint64_t* seeds, float* const* out, const size_t* out_cap) {
     GOMEL_TRY return from_mel_batch_guarded(h, n_utt, (const void* const*)mel, n_pairs, (const void* const*)x0, seeds, (void* const*)out, out_cap, 1); GOMEL_CATCH
+}
+int gomel_from_mel_batch_submit(gomel_handle* h, size_t n_utt, const double* const* mel, const size_t* n_pairs, const double* const* x0,
+                                const uint64_t* seeds, double* const* out, const size_t* out_cap, gomel_job** job) {
+    GOMEL_TRY return submit_guarded(h, n_utt, (const void* const*)mel, n_pairs, (const void* const*)x0, seeds, (void* const*)out, out_cap, 0, job); GOMEL_CATCH
+}
+int gomel_from_mel_batch_submit_f32(gomel_handle* h, size_t n_utt, const float* const* mel, const size_t* n_pairs, const float* const* x0,
+                                    const uint64_t* seeds, float* const* out, const size_t* out_cap, gomel_job** job) {
+    GOMEL_TRY return submit_guarded(h, n_utt, (const void* const*)mel, n_pairs, (const void* const*)x0, seeds, (void* const*)out, out_cap, 1, job); GOMEL_CATCH
+}
+int gomel_job_wait(gomel_job* job) {
+    GOMEL_TRY return job_wait_guarded(job); GOMEL_CATCH
+}
+int gomel_job_poll(gomel_job* job, int* finished) {
+    if (!job || !finished) return GOMEL_ERR_NULL;
+    if (job->completed) { *finished = 1; return GOMEL_OK; }
+    DeviceGuard dg(job->h->device); HIPCHK(dg.err);
+    const hipError_t e = hipEventQuery(job->down);
+    if (e != hipSuccess && e != hipErrorNotReady) { g_last_hip = (int)e; return GOMEL_ERR_HIP; }
+    if (e == hipErrorNotReady) (void)hipGetLastError();
+    *finished = e == hipSuccess;
+    return GOMEL_OK;
 }
 int gomel_from_mel_batch_multi(gomel_handle* const* handles, size_t n_handles, size_t n_utt, const double* const* mel, const size_t* n_pairs,
                                const double* const* x0, const uint64_t* seeds, double* const* out, const size_t* out_cap) {

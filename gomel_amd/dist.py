@@ -3,6 +3,11 @@ between FromMel calls).  One process per GPU; contiguous utterance shards balanc
 collective.  The only collective is the one-off broadcast of the table blob ("mel basis": Hann window + undomel/domel
 tables) from rank 0 -- over RCCL/xGMI with the "nccl" backend, over gloo in the CPU tests.
 """
+import json
+import os
+import re
+import subprocess
+
 import numpy as np
 
 
@@ -72,3 +77,82 @@ def from_mel_sharded(compute, mels, x0s=None, seeds=None, rank=0, world=1, gathe
     parts = [None] * world
     dist.all_gather_object(parts, local)
     return [w for p in parts for w in p]
+
+
+# ------------------------------------------------------------------------------------------------ rank -> NUMA node
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_bus_ids(smi="rocm-smi", timeout=30):
+    """PCI bus ids of the GPUs in the order rocm-smi lists them (`rocm-smi --showbus --json`, a CHILD process: nothing in this
+    process touches the GPU).  [] when the tool is missing or says nothing usable."""
+    try:
+        out = subprocess.run([smi, "--showbus", "--json"], capture_output=True, text=True, timeout=timeout).stdout
+        data = json.loads(out[out.index("{"):])
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return []
+    cards = sorted((k for k in data if re.fullmatch(r"card\d+", k)), key=lambda k: int(k[4:]))
+    ids = []
+    for k in cards:
+        bdf = next((str(v) for kk, v in data[k].items() if "bus" in kk.lower()), None)
+        if bdf is None:
+            return []
+        ids.append(bdf.strip().lower())
+    return ids
+
+
+def visible_index(local_rank, env=None):
+    """The physical GPU index behind this rank's device ordinal: through ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when they hold
+    plain indices (the launcher's usual form), else the ordinal itself."""
+    env = os.environ if env is None else env
+    idx = local_rank
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):   # applied innermost first
+        v = env.get(var, "").strip()
+        if not v:
+            continue
+        parts = [p.strip() for p in v.split(",")]
+        if not all(p.isdigit() for p in parts) or idx >= len(parts):
+            return None                                    # UUIDs or a short list: do not guess
+        idx = int(parts[idx])
+    return idx
+
+
+def bind_to_gpu_numa_node(local_rank, sysfs="/sys", bus_ids=None, env=None, setaffinity=None, getaffinity=None):
+    """Before any GPU call: restrict this process to the CPUs of the NUMA node its GPU hangs off, so that pinned host buffers
+    (gomel_host_alloc) are first-touched in memory local to the GPU's root port and the rank's copy threads run there -- every rank
+    moves tens of GB/s of pinned host traffic (PCIe, not xGMI, is the 8-GPU limiter).  The node comes from
+    <sysfs>/bus/pci/devices/<bdf>/numa_node, its CPUs from <sysfs>/devices/system/node/node<N>/cpulist, intersected with the
+    current affinity mask.  Returns a dict saying what was done ({"bound": False, "why": ...} when anything is missing: no NUMA
+    information is not an error).  sysfs / bus_ids / env / the affinity calls are injectable for the CPU tests."""
+    setaffinity = setaffinity or (lambda cpus: os.sched_setaffinity(0, cpus))
+    getaffinity = getaffinity or (lambda: os.sched_getaffinity(0))
+    idx = visible_index(local_rank, env)
+    if idx is None:
+        return {"bound": False, "why": "device visibility is not a list of indices"}
+    ids = gpu_bus_ids() if bus_ids is None else list(bus_ids)
+    if idx >= len(ids):
+        return {"bound": False, "why": "no PCI bus id for GPU %d (%d listed)" % (idx, len(ids))}
+    bdf = ids[idx]
+    try:
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return {"bound": False, "why": "no numa_node for %s" % bdf, "bdf": bdf}
+    if node < 0:
+        return {"bound": False, "why": "numa_node = -1 (single-node machine or not reported)", "bdf": bdf}
+    try:
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")).read())
+    except (OSError, ValueError):
+        return {"bound": False, "why": "no cpulist for node %d" % node, "bdf": bdf, "numa_node": node}
+    have = set(getaffinity())
+    use = cpus & have
+    if not use:
+        return {"bound": False, "why": "node %d's CPUs are outside this process's affinity mask" % node, "bdf": bdf, "numa_node": node}
+    setaffinity(use)
+    return {"bound": True, "bdf": bdf, "numa_node": node, "cpus": len(use), "of_allowed": len(have)}

@@ -86,12 +86,25 @@ class Engine:
     def set_path(self, mode):
         check(_lib.lib().gomel_set_path(self._h, int(mode)), "gomel_set_path")
 
+    def set_call_mode(self, mode):
+        """gomel_set_call_mode: 1 = every synchronous batch call is one whole batch (submit + wait), for callers that overlap calls
+        from several threads; 0 (default) = chunked."""
+        check(_lib.lib().gomel_set_call_mode(self._h, int(mode)), "gomel_set_call_mode")
+
     def set_precision(self, bits):
         check(_lib.lib().gomel_set_precision(self._h, int(bits)), "gomel_set_precision")
 
     def set_precision_schedule(self, fp64_iterations):
-        """The first `fp64_iterations` iterations of every call in fp64, the rest in fp32 (gomel_set_precision_schedule)."""
-        check(_lib.lib().gomel_set_precision_schedule(self._h, int(fp64_iterations)), "gomel_set_precision_schedule")
+        """The first `fp64_iterations` iterations of every call in fp64, the rest in fp32 (gomel_set_precision_schedule);
+        "auto" (or _lib.SCHEDULE_AUTO) = the calibrated default."""
+        k = _lib.SCHEDULE_AUTO if fp64_iterations == "auto" else int(fp64_iterations)
+        check(_lib.lib().gomel_set_precision_schedule(self._h, k), "gomel_set_precision_schedule")
+
+    def fp64_iterations(self, iterations=-1):
+        """gomel_get_precision: how many of a call's iterations run in fp64 under the engine's current mode."""
+        k = ctypes.c_int32(0)
+        check(_lib.lib().gomel_get_precision(self._h, int(iterations), ctypes.byref(k)), "gomel_get_precision")
+        return k.value
 
     def plan_chunks(self, n_pairs):
         """gomel_plan_chunks: how a gomel_from_mel_batch call over utterances of these lengths is cut -- the utterance indices
@@ -240,6 +253,24 @@ class Engine:
                                               bound.caps.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t))), "gomel_from_mel_batch")
         return bound.views
 
+    def submit_bound(self, bound, seeds=None):
+        """gomel_from_mel_batch_submit on bound buffers: queues the call (upload | whole-batch kernels | download on three streams)
+        and returns a Job at once; Job.wait() blocks until the waveforms are in the bound `outs`.  Keep two jobs in flight and the
+        copies of one hide behind the kernels of the other.  The bound buffers must not be touched until the job has been waited for."""
+        if bound.engine is not self:
+            raise ValueError("buffers were bound to another engine")
+        n = bound.n
+        sp = None if seeds is None else np.array([int(s_) & (2 ** 64 - 1) for s_ in seeds], dtype=np.uint64)
+        if sp is not None and len(sp) != n:
+            raise ValueError("one seed per utterance")
+        dpp = ctypes.POINTER(c_double_p)
+        job = ctypes.c_void_p()
+        check(_lib.lib().gomel_from_mel_batch_submit(self._h, n, bound.mp.ctypes.data_as(dpp), bound.npairs.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)),
+                                                     None if bound.xp is None else bound.xp.ctypes.data_as(dpp),
+                                                     None if sp is None else sp.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), bound.op.ctypes.data_as(dpp),
+                                                     bound.caps.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), ctypes.byref(job)), "gomel_from_mel_batch_submit")
+        return Job(job, bound)
+
     def target_magnitudes(self, mel_pairs):
         m = _as_pairs(mel_pairs)
         H = self.cfg.resolut // 2
@@ -294,6 +325,34 @@ class Engine:
         out = np.empty((s.shape[0], N), dtype=np.float32)
         check(_lib.lib().gomel_irfft_frames(self._h, buf.ctypes.data_as(_lib.c_float_p), s.shape[0], out.ctypes.data_as(_lib.c_float_p)), "gomel_irfft_frames")
         return out
+
+
+class Job:
+    """A submitted call (gomel_job): wait() returns the bound output views once the waveforms have landed; every job must be waited for."""
+
+    def __init__(self, handle, bound):
+        self._j, self._bound = handle, bound
+
+    def done(self):
+        if not self._j:
+            return True
+        f = ctypes.c_int(0)
+        check(_lib.lib().gomel_job_poll(self._j, ctypes.byref(f)), "gomel_job_poll")
+        return bool(f.value)
+
+    def wait(self):
+        if self._j:
+            j, self._j = self._j, None
+            check(_lib.lib().gomel_job_wait(j), "gomel_job_wait")
+        return self._bound.views
+
+    def __del__(self):
+        try:
+            if self._j:
+                _lib.lib().gomel_job_wait(self._j)
+                self._j = None
+        except Exception:
+            pass
 
 
 class Batch:
@@ -394,8 +453,10 @@ class Mel:
         # not in the reference: which GPU, and which Hann definition (see DESIGN.md "window")
         self.Device = -1
         self.HannPeriodic = False
-        self.Precision = 32           # 32: fp32 kernels (default); 64: fp64 "precise" mode (gomel_set_precision)
-        self.Fp64Iterations = None    # with Precision 64: only the first so many iterations in fp64, the rest fp32 (gomel_set_precision_schedule)
+        # arithmetic of the iterations (gomel_set_precision): 0 = AUTOMATIC (default): the calibrated fp64-then-fp32 schedule, within
+        # 1e-4 RMS of the reference's float64 loop (mel/mel.go:76-139); 32 = fp32 throughout, the opt-in fast mode; 64 = fp64 throughout
+        self.Precision = 0
+        self.Fp64Iterations = None    # an int: explicit schedule -- that many iterations in fp64, the rest fp32 (gomel_set_precision_schedule); overrides Precision
         self._engines = {}
 
     def _config(self):
@@ -417,8 +478,8 @@ class Mel:
                 old.close()           # one live handle per Mel object: the one being replaced is released now, not at GC time
             e = Engine(c)
             self._engines = {key: e}
-            e._precision = (32, None)
-        want = (int(self.Precision), None if self.Fp64Iterations is None or int(self.Precision) != 64 else int(self.Fp64Iterations))
+            e._precision = (0, None)
+        want = (int(self.Precision), None if self.Fp64Iterations is None else int(self.Fp64Iterations))
         if e._precision != want:
             if want[1] is None:
                 e.set_precision(want[0])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOMEL_HIP_ABI_VERSION 3
+#define GOMEL_HIP_ABI_VERSION 4
 
 typedef enum gomel_status {
     GOMEL_OK = 0,
@@ -144,10 +144,30 @@ int gomel_from_mel_batch(gomel_handle* h, size_t n_utt, const double* const* mel
 
 /* fp32 host I/O: the same call for callers whose spectrograms and waveforms are float (an acoustic model's output,
  * a float PCM sink): half the PCIe bytes.  The log-mel values are taken as given (converted to double on the device, then the
- * fp64 table arithmetic of gomel_from_mel); the waveform is the fp32 result of the iteration without the final widening.
- * Not available on a handle in 64-bit precision mode (GOMEL_ERR_BAD_CONFIG); the generic frame lengths take it (fp64 inside). */
+ * fp64 table arithmetic of gomel_from_mel); the iterations run in the handle's precision mode (automatic schedule, fp32, fp64: float
+ * at the boundary, the mode's arithmetic inside) and the waveform is rounded to float once, at the end. */
 int gomel_from_mel_batch_f32(gomel_handle* h, size_t n_utt, const float* const* mel_pairs, const size_t* n_pairs,
                              const float* const* x0, const uint64_t* seeds, float* const* out, const size_t* out_cap);
+
+/* Calls in flight (SURVEY 8(b) "Threading", 8(d) metric: wall time of gomel_from_mel_batch INCLUDING H2D and D2H).  A bulk caller
+ * that keeps two calls in flight hides every copy behind the other call's kernels: gomel_from_mel_batch_submit queues one call --
+ * upload, every kernel in whole-batch launches, download, on three streams -- and returns; gomel_job_wait blocks until the waveforms
+ * are in `out` and frees the job (every submitted job must be waited for, in any order; a wait returns the call's status).
+ * `mel_pairs[u]`, `x0[u]` and `out[u]` must stay valid and untouched until the wait returns; the pointer ARRAYS themselves are read
+ * during submit only.  Arguments as gomel_from_mel_batch.  A call too small for the fused kernels runs inside submit and comes back
+ * as a finished job.  gomel_job_poll: *finished = 1 once a wait would not block.
+ * gomel_set_call_mode(h, 1) makes the synchronous gomel_from_mel_batch / _f32 do the same (one submit + wait per call): for hosts
+ * that overlap calls on one handle from several threads (two goroutines calling in a loop then pipeline at whole-batch granularity);
+ * 0 (default) = the chunked call, the best a lone synchronous caller gets.  The two modes cut utterances into different segments,
+ * so their results differ at rounding level (other summation order of the overlap-add); within a mode results are bit-reproducible. */
+typedef struct gomel_job gomel_job;
+int gomel_from_mel_batch_submit(gomel_handle* h, size_t n_utt, const double* const* mel_pairs, const size_t* n_pairs,
+                                const double* const* x0, const uint64_t* seeds, double* const* out, const size_t* out_cap, gomel_job** job);
+int gomel_from_mel_batch_submit_f32(gomel_handle* h, size_t n_utt, const float* const* mel_pairs, const size_t* n_pairs,
+                                    const float* const* x0, const uint64_t* seeds, float* const* out, const size_t* out_cap, gomel_job** job);
+int gomel_job_wait(gomel_job* job);
+int gomel_job_poll(gomel_job* job, int* finished);
+int gomel_set_call_mode(gomel_handle* h, int mode);
 
 /* One call, several GPUs of one node (SURVEY 8e "one host thread/stream per device"): `handles` holds one handle per device,
  * all created from the same configuration (gomel_create_from_tables gives them bit-identical tables); the utterances are cut
@@ -197,17 +217,33 @@ int gomel_batch_destroy(gomel_batch* b);
  * resident, the launch gives up after 20 ms, the batch is recomputed with the generic kernels (same results, bit for bit) and
  * the handle leaves that path alone for its next 64 batches (doubling with every further timeout, up to 4096). */
 int gomel_set_path(gomel_handle* h, int mode);
-/* Arithmetic of the Griffin-Lim iteration for batches created afterwards: 32 (default: fp32 kernels, the benchmarked path) or
- * 64 ("precise": the generic kernels in fp64 end to end, ~1e-12 from the fp64 reference arithmetic, several times slower). */
+/* Arithmetic of the Griffin-Lim iterations (mel/mel.go:85-136 is float64 / complex128 throughout) for batches created afterwards:
+ *   0  (default) AUTOMATIC: the calibrated precision schedule gomel_auto_fp64_iterations(cfg, I) -- the call a caller gets without
+ *      a knob ends within 1e-4 RMS of the reference's float64 arithmetic on every utterance of the calibration sets (below);
+ *   32 fp32 kernels for every iteration: the opt-in FAST mode (1.4x the default's rate at 60 iterations).  Typically 1e-6 from the
+ *      fp64 arithmetic, but ~1 % of 60-iteration utterances end beyond 1e-4;
+ *   64 fp64 kernels for every iteration (~1e-13 from the fp64 restatement of the reference): the mode that is guaranteed on every input. */
 int gomel_set_precision(gomel_handle* h, int bits);
-/* Precision schedule, the parity mode at a lower price: the first `fp64_iterations` Griffin-Lim iterations of every call run the
- * fp64 kernels, the remaining ones the fp32 kernels (the signal is rounded to fp32 once, at the hand-over).  Griffin-Lim on a
- * spectrogram that is not consistent amplifies a rounding-level perturbation by every iteration that FOLLOWS it
- * (mel/mel.go:85-136 is not a contraction there), so fp32 rounding only in the last iterations stays near 1e-7 where fp32
- * throughout can end 1e-4 away from the reference's float64 arithmetic.  0 = fp32 throughout
- * (= gomel_set_precision(h, 32)); negative, or not below the call's iteration count = fp64 throughout (= 64).  Applies to the
- * batches the fused kernel takes; smaller batches and the generic frame lengths run fp64 throughout under any schedule. */
+/* Precision schedule: the first `fp64_iterations` Griffin-Lim iterations of every call run the fp64 kernels, the remaining ones the
+ * fp32 kernels (the signal is rounded to fp32 once, at the hand-over).  Griffin-Lim on a spectrogram that is not consistent
+ * amplifies a rounding-level perturbation by every iteration that FOLLOWS it, and it is most unstable in its first iterations, from
+ * the random initial signal (mel/mel.go:80-83): fp32 rounding confined to the later iterations stays near 1e-7 where fp32
+ * throughout can end 1e-4 away from the reference's float64 arithmetic.
+ *   GOMEL_SCHEDULE_AUTO = the calibrated schedule (= gomel_set_precision(h, 0), the default);
+ *   0 = fp32 throughout (= gomel_set_precision(h, 32)); negative, or not below the call's iteration count = fp64 throughout (= 64).
+ * A schedule applies to the batches the fused kernels take; smaller batches (one utterance, a handful) and the generic frame
+ * lengths run fp64 throughout whenever the schedule asks for any fp64 iteration at all. */
+#define GOMEL_SCHEDULE_AUTO (-2147483647 - 1)
 int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations);
+/* The automatic schedule: of a call of `iterations` Griffin-Lim iterations, how many run in fp64 first (0 = none: the reference's
+ * shipped GriffinLimIterations = 2, mel/mel.go:39, stays pure fp32).  Host logic only.  Calibrated on the GPU for iterations in
+ * {2, 5, 10, 20, 30, 40, 60, 100} on the towav, TTS and NewMel-default geometries, 4096 random and 4096 signal-derived utterances
+ * each: the smallest k that left no utterance beyond 3e-5 RMS of fp64 throughout (profiles/r04/calibration/); interpolated upwards
+ * in between.  Generic frame lengths: = iterations (their kernels are fp64).  Negative iterations / NULL cfg: 0. */
+int32_t gomel_auto_fp64_iterations(const gomel_config* cfg, int32_t iterations);
+/* What a call of `iterations` iterations (negative: the handle's GriffinLimIterations) on this handle will do under its current
+ * mode: *fp64_iterations = 0 (fp32 throughout) ... iterations (fp64 throughout). */
+int gomel_get_precision(const gomel_handle* h, int32_t iterations, int32_t* fp64_iterations);
 
 /* (*Mel).ToMel, mel/mel.go:46-74 = pad + gossp STFT + |S[j]|,|S[N-1-j]| + domel + ln(max(v,1e-5)). */
 size_t gomel_to_mel_pairs(const gomel_config* cfg, size_t n_samples);

@@ -45,7 +45,7 @@ def test_default_config_is_newmel(L):
     assert L.gomel_default_config(ctypes.byref(c)) == 0
     assert (c.num_mels, c.window, c.resolut, c.griffin_lim_iterations) == (160, 256, 2048, 2)     # mel/mel.go:30-41
     assert (c.mel_fmin, c.mel_fmax, c.tune_mul, c.tune_add) == (0.0, 8000.0, 1.0, 0.0)
-    assert L.gomel_abi_version() == 3
+    assert L.gomel_abi_version() == 4
 
 
 def test_length_helpers_match_oracle(L, oracle):
@@ -70,6 +70,37 @@ def test_length_helpers_match_oracle(L, oracle):
     cfg = oracle.towav_config()
     assert L.gomel_to_mel_pairs(ctypes.byref(c), 441000) == 342 * 192
     assert L.gomel_to_mel_pairs(ctypes.byref(c), 22050) == oracle.num_frames(len(oracle.pad(np.zeros(22050), 1280)), 4096, 1280) * cfg.NumMels
+
+
+def test_automatic_precision_schedule_table(L):
+    """gomel_auto_fp64_iterations (host logic): the calibrated points of profiles/r04/calibration/TABLE.txt -- the smallest k that left
+    none of 24 576 utterances beyond 3e-5 -- interpolated UPWARDS in between, never above the iteration count, monotone, trailing fp32
+    iterations held at 20 beyond the last point; the reference's shipped 2 iterations (mel/mel.go:39) run one of them in fp64 (two fp32
+    iterations already leave 2 of 24 576 utterances beyond 3e-5); generic frame lengths are fp64 throughout."""
+    import re
+    from gomel_amd._lib import GomelConfig, SCHEDULE_AUTO
+    c = GomelConfig()
+    L.gomel_default_config(ctypes.byref(c))
+    k = lambda i: L.gomel_auto_fp64_iterations(ctypes.byref(c), i)
+    table = {2: 1, 5: 3, 10: 6, 20: 10, 30: 25, 40: 30, 60: 35, 100: 80}
+    txt = open(os.path.join(ROOT, "profiles", "r04", "calibration", "TABLE.txt")).read()
+    committed = eval(re.search(r"beyond 3e-5 in any set: (\{.*\})", txt).group(1))
+    assert committed == table                                             # the code's points ARE the committed calibration's
+    assert [k(i) for i in sorted(table)] == [table[i] for i in sorted(table)]
+    assert k(0) == 0 and k(-3) == 0 and k(1) == 1 and L.gomel_auto_fp64_iterations(None, 60) == 0
+    ks = [k(i) for i in range(0, 400)]
+    assert all(0 <= v <= i for i, v in enumerate(ks)) and all(b >= a for a, b in zip(ks, ks[1:]))
+    assert k(50) == 33 and k(45) == 32 and k(101) == 81 and k(300) == 280   # rounded up between points; 20 trailing fp32 iterations beyond
+    for n in (1000, 4095, 8192):
+        c.resolut = n
+        assert k(60) == 60
+    assert SCHEDULE_AUTO == -2 ** 31
+    src = open(os.path.join(ROOT, "include", "gomel_hip.h")).read()
+    assert "#define GOMEL_SCHEDULE_AUTO (-2147483647 - 1)" in src
+    assert L.gomel_get_precision(None, 60, None) == 7 and L.gomel_set_call_mode(None, 1) == 7 and L.gomel_job_wait(None) == 7
+    assert L.gomel_job_poll(None, None) == 7
+    j = ctypes.c_void_p()
+    assert L.gomel_from_mel_batch_submit(None, 1, None, None, None, None, None, None, ctypes.byref(j)) == 7 and not j
 
 
 def test_no_device_means_error_not_fallback(L):

@@ -79,3 +79,42 @@ def test_sharded_results_equal_single_process_gloo_world2(oracle):
         assert outs == single                          # sharding + gather is bitwise invisible, on every rank
         assert blob == b"mel-basis-\x00\x01\x02" * 1000
         assert tables == b"tables-built-by-rank-0"     # every rank created its engine from rank 0's blob
+
+
+def test_rank_binds_to_the_cpus_of_its_gpus_numa_node(tmp_path):
+    """bind_to_gpu_numa_node on a fake sysfs tree: two GPUs on two nodes, the visibility variables mapped through, the affinity mask
+    intersected; missing information leaves the process unbound and says why."""
+    from gomel_amd import dist as gd
+    sysfs = tmp_path / "sys"
+    for bdf, node in (("0000:05:00.0", 0), ("0000:85:00.0", 1), ("0000:c5:00.0", -1)):
+        d = sysfs / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    for node, cpus in ((0, "0-3,16-19"), (1, "4-7,20-23")):
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    ids = ["0000:05:00.0", "0000:85:00.0", "0000:c5:00.0"]
+    got = {}
+    allowed = set(range(0, 24))
+    kw = dict(sysfs=str(sysfs), bus_ids=ids, setaffinity=lambda c: got.__setitem__("cpus", set(c)), getaffinity=lambda: allowed)
+    r = gd.bind_to_gpu_numa_node(1, env={}, **kw)
+    assert r["bound"] and r["numa_node"] == 1 and got["cpus"] == {4, 5, 6, 7, 20, 21, 22, 23} and r["cpus"] == 8
+    r = gd.bind_to_gpu_numa_node(0, env={"HIP_VISIBLE_DEVICES": "1,0"}, **kw)           # ordinal 0 is physical GPU 1
+    assert r["bound"] and r["bdf"] == "0000:85:00.0"
+    r = gd.bind_to_gpu_numa_node(0, env={"HIP_VISIBLE_DEVICES": "1", "ROCR_VISIBLE_DEVICES": "2,0"}, **kw)   # HIP index 1 of ROCR's list -> GPU 0
+    assert r["bound"] and r["bdf"] == "0000:05:00.0" and got["cpus"] == {0, 1, 2, 3, 16, 17, 18, 19}
+    got.clear()
+    allowed = {0, 1, 4}
+    kw["getaffinity"] = lambda: allowed
+    r = gd.bind_to_gpu_numa_node(1, env={}, **kw)                                        # cgroup / taskset mask respected
+    assert r["bound"] and got["cpus"] == {4}
+    for rank, env, why in ((2, {}, "numa_node = -1"), (5, {}, "no PCI bus id"), (0, {"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}, "not a list of indices")):
+        got.clear()
+        r = gd.bind_to_gpu_numa_node(rank, env=env, **kw)
+        assert not r["bound"] and why in r["why"] and not got
+    allowed = {8, 9}
+    r = gd.bind_to_gpu_numa_node(0, env={}, **kw)
+    assert not r["bound"] and "outside" in r["why"]
+    assert gd.gpu_bus_ids(smi="/nonexistent/rocm-smi") == []
+    assert gd._parse_cpulist("0-2,7,9-10\n") == {0, 1, 2, 7, 9, 10}

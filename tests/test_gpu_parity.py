@@ -7,7 +7,7 @@ import math
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp32_start_mode")]   # these tests target the fp32 kernels unless they select a mode (conftest.py)
 
 RMS_TOL = 1e-4  # north_star: "matching the reference FromMel output sample-for-sample within 1e-4 RMS"
 

@@ -11,10 +11,10 @@ import sys
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp32_start_mode")]   # these tests target the fp32 kernels unless they select a mode (conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RMS_TOL = 1e-4          # north_star: sample-for-sample within 1e-4 RMS
-PARITY_SCHEDULE = 30    # gomel_set_precision_schedule: iterations run in fp64 before the fp32 kernel takes over (bench.py's `precise.schedule`)
+AUTO_60 = 35            # gomel_auto_fp64_iterations(cfg, 60): fp64 iterations of the DEFAULT call at 60 iterations (profiles/r04/calibration/TABLE.txt)
 
 T = dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096)     # towav geometry (cmd/towav/main.go:30-37)
 S = dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024)        # BASELINE configs[3], the TTS geometry
@@ -38,14 +38,16 @@ def cfg3_inputs(U, F, K):
 
 
 # ------------------------------------------------------------------------------------------------ full-size configurations
-def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
+def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle, monkeypatch):
     """BASELINE configs[2] (256 x 192 mels x 400 frames, N 4096 / hop 1280, 60 iterations): ALL 256 utterances against the C
     restatement of mel.go:76-152, true fp64 x0 on both sides.
 
-    The PARITY modes carry hard assertions on every utterance: 64-bit mode must match everywhere (it does to ~1e-13: same
-    arithmetic, two implementations), the precision schedule (fp64 first, fp32 last) must stay under the north-star's 1e-4.
+    The DEFAULT call -- a handle nobody has turned a knob on: the calibrated precision schedule, gomel_auto_fp64_iterations -- carries
+    the HARD assertion: every utterance under the north-star's 1e-4.  So does 64-bit mode (it matches to ~1e-13: same arithmetic,
+    two implementations).
 
-    The plain fp32 kernels (the throughput default) get a STATISTICAL check -- what the arithmetic can promise on THESE inputs.  iid-random
+    The fp32 kernels throughout (the OPT-IN fast mode, gomel_set_precision(h, 32)) get a STATISTICAL check, named as such -- what that
+    arithmetic can promise on THESE inputs.  iid-random
     log-mel is not the spectrogram of any signal: Griffin-Lim does not converge on it (after 60 iterations every hop block still
     moves by ~1e-2 of the signal per iteration, spectral convergence 0.46) and the map has locally unstable directions, so a
     perturbation of one part in 1e7 -- fp32 rounding, or rounding the INPUT magnitudes to fp32 -- grows by 1.1-1.4x per iteration
@@ -60,13 +62,13 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
     cfg = oracle.MelConfig(**fields)
     L = oracle.out_len(cfg, F * K)
     want, _ = coracle.from_mel_batch(cfg, mels, [oracle.x0_splitmix(s, L) for s in seeds], threads=min(16, os.cpu_count() or 1))
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)                   # the handle as a caller gets it: no knob, no environment
     m = mel_obj(fields)
     eng = m.engine()
+    assert eng.fp64_iterations() == AUTO_60
 
     def run(bits):
-        if bits == "schedule":
-            eng.set_precision_schedule(PARITY_SCHEDULE)
-        else:
+        if bits != "default":                                               # "default": nothing is set on the handle
             eng.set_precision(bits)
         b = gomel_amd.Batch(eng, [F * K] * U)
         b.upload(mels, None, seeds)
@@ -78,21 +80,21 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
         assert all(np.array_equal(a, c) for a, c in zip(o1, o2))            # run-to-run bitwise (no atomics)
         return o1
 
+    # the DEFAULT call (first AUTO_60 iterations fp64, the rest fp32): HARD bar on every utterance
+    odef = run("default")
+    edef = np.array([rms(a - w) for a, w in zip(odef, want)])
+    print("config 3, DEFAULT call (%d fp64 + %d fp32 iterations) vs oracle: median %.2e p99 %.2e max %.2e" % (
+        AUTO_60, 60 - AUTO_60, np.median(edef), np.percentile(edef, 99), edef.max()))
+    assert edef.max() < RMS_TOL, (edef.max(), int(np.argmax(edef)))
     o64 = run(64)
     e64 = np.array([rms(a - w) for a, w in zip(o64, want)])
     print("config 3, 64-bit mode vs oracle: max %.2e" % e64.max())
     assert e64.max() < 1e-9
-    # the precision schedule (first PARITY_SCHEDULE iterations fp64, the rest fp32): HARD bar on every utterance
-    osch = run("schedule")
-    esch = np.array([rms(a - w) for a, w in zip(osch, want)])
-    print("config 3, schedule (%d fp64 + %d fp32 iterations) vs oracle: median %.2e p99 %.2e max %.2e" % (
-        PARITY_SCHEDULE, 60 - PARITY_SCHEDULE, np.median(esch), np.percentile(esch, 99), esch.max()))
-    assert esch.max() < RMS_TOL, (esch.max(), int(np.argmax(esch)))
-    o32 = run(32)
+    o32 = run(32)                                                           # the opt-in fast mode: statistical check
     e32 = np.array([rms(a - w) for a, w in zip(o32, want)])
     sig = np.array([rms(w) for w in want])
     over = np.flatnonzero(e32 > RMS_TOL)
-    print("config 3, fp32 kernels vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e, over 1e-4: %s (signal rms %.3f)" % (
+    print("config 3, fp32 throughout (opt-in fast mode) vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e, over 1e-4: %s (signal rms %.3f)" % (
         np.median(e32), np.percentile(e32, 90), np.percentile(e32, 99), e32.max(), over.tolist(), sig.mean()))
     assert all(np.isfinite(o).all() and o.shape == (L,) for o in o32)
     assert np.median(e32) < 1e-5 and np.percentile(e32, 90) < 5e-5
@@ -105,11 +107,17 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle):
         assert (blocks > 1e-4).sum() <= 12, (u, int((blocks > 1e-4).sum()))
 
 
-def test_config2_full_size_single_utterance_automatic_path(oracle, coracle):
+@pytest.mark.parametrize("mode", ["default", 32])
+def test_config2_full_size_single_utterance_automatic_path(oracle, coracle, monkeypatch, mode):
     """BASELINE configs[1]: one 10 s utterance @44.1 kHz (342 frames of the survey's chirp + AM tone + noise through ToMel), 60
-    iterations, the path the library picks by itself for a batch of this size."""
+    iterations, the path the library picks by itself for a batch of this size -- as a caller gets it without a knob (a batch this
+    small runs fp64 throughout under the default schedule), and in the fp32 fast mode."""
     fields = dict(T, GriffinLimIterations=60)
+    if mode == "default":
+        monkeypatch.delenv("GOMEL_PRECISION", raising=False)
     m = mel_obj(fields)
+    if mode != "default":
+        m.Precision = mode
     sig = oracle.config2_signal()
     mel = m.ToMel(sig)
     assert len(mel) == 342 * 192
@@ -117,28 +125,28 @@ def test_config2_full_size_single_utterance_automatic_path(oracle, coracle):
     x0 = oracle.x0_splitmix(1, oracle.out_len(cfg, len(mel)))
     got = m.FromMel(mel.copy(), x0=x0)
     want, _ = coracle.from_mel(cfg, mel, x0)
-    print("config 2 (342 frames x 60 iterations) vs oracle: %.2e (signal rms %.3f)" % (rms(got - want), rms(want)))
-    assert rms(got - want) < RMS_TOL
+    print("config 2 (342 frames x 60 iterations), %s vs oracle: %.2e (signal rms %.3f)" % (mode, rms(got - want), rms(want)))
+    assert rms(got - want) < (1e-8 if mode == "default" else RMS_TOL)
 
 
-def test_config4_full_size_tts_batch(oracle, coracle):
+def test_config4_full_size_tts_batch(oracle, coracle, monkeypatch):
     """BASELINE configs[3]: 256 x 400 frames at N 1024 / hop 256 / 80 mels, 60 iterations, ALL 256 utterances against the C
-    oracle: run-to-run determinism of the whole batch; hard assertions for the parity modes (64-bit: 1e-9, precision schedule:
-    the north-star's 1e-4, every utterance); the statistical check for the plain fp32 kernels (as at config 3)."""
+    oracle: run-to-run determinism of the whole batch; HARD assertions for the DEFAULT call (no knob: the calibrated schedule; the
+    north-star's 1e-4 on every utterance) and for 64-bit mode (1e-9); the statistical check for the opt-in fp32 fast mode (as at config 3)."""
     import gomel_amd
     fields = dict(S, GriffinLimIterations=60)
     U, F, K = 256, 400, 80
     mels, seeds = cfg3_inputs(U, F, K)
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)                   # the handle as a caller gets it
     m = mel_obj(fields)
     eng = m.engine()
+    assert eng.fp64_iterations() == AUTO_60
     cfg = oracle.MelConfig(**fields)
     L = oracle.out_len(cfg, F * K)
     want, _ = coracle.from_mel_batch(cfg, mels, [oracle.x0_splitmix(s, L) for s in seeds], threads=min(16, os.cpu_count() or 1))
 
     def run(mode):
-        if mode == "schedule":
-            eng.set_precision_schedule(PARITY_SCHEDULE)
-        else:
+        if mode != "default":
             eng.set_precision(mode)
         b = gomel_amd.Batch(eng, [F * K] * U)
         b.upload(mels, None, seeds)
@@ -150,16 +158,16 @@ def test_config4_full_size_tts_batch(oracle, coracle):
         assert all(np.array_equal(a, c) for a, c in zip(o1, o2))               # run-to-run bitwise
         return np.array([rms(a - w) for a, w in zip(o1, want)])
 
+    edef = run("default")
+    print("config 4, DEFAULT call (%d fp64 + %d fp32 iterations) vs oracle: median %.2e p99 %.2e max %.2e" % (
+        AUTO_60, 60 - AUTO_60, np.median(edef), np.percentile(edef, 99), edef.max()))
+    assert edef.max() < RMS_TOL, (edef.max(), int(np.argmax(edef)))
     e64 = run(64)
     print("config 4, 64-bit mode vs oracle: max %.2e" % e64.max())
     assert e64.max() < 1e-9
-    esch = run("schedule")
-    print("config 4, schedule (%d fp64 + %d fp32 iterations) vs oracle: median %.2e p99 %.2e max %.2e" % (
-        PARITY_SCHEDULE, 60 - PARITY_SCHEDULE, np.median(esch), np.percentile(esch, 99), esch.max()))
-    assert esch.max() < RMS_TOL, (esch.max(), int(np.argmax(esch)))
     e32 = run(32)
     over = np.flatnonzero(e32 > RMS_TOL)
-    print("config 4, fp32 kernels vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e, over 1e-4: %s" % (
+    print("config 4, fp32 throughout (opt-in fast mode) vs oracle: median %.2e p90 %.2e p99 %.2e max %.2e, over 1e-4: %s" % (
         np.median(e32), np.percentile(e32, 90), np.percentile(e32, 99), e32.max(), over.tolist()))
     assert np.median(e32) < 1e-5 and np.percentile(e32, 90) < 5e-5 and len(over) <= max(1, U // 100) + 1, over   # statistical
 
@@ -227,10 +235,26 @@ def test_fp32_host_io_entry(oracle):
     ref2 = e.from_mel_batch([mm.astype(np.float64) for mm in mels], [x.astype(np.float64) for x in x0], None)
     for a, r in zip(got2, ref2):
         assert rms(a.astype(np.float64) - r) < 1e-6
-    e.set_precision(64)
-    import gomel_amd
-    with pytest.raises(gomel_amd.GomelError):
-        e.from_mel_batch_f32(mels, None, seeds)
+    # every precision mode takes float host buffers (round 4): float at the boundary, the mode's arithmetic inside -- the waveform is
+    # the float64 interface's, rounded to float once; on the persistent / generic kernels (these three utterances) and on the fused
+    # kernels (path 2: 64-bit mode, an explicit schedule, the automatic one)
+    for path in (0, 2):
+        e.set_path(path)
+        for mode in (64, "schedule", "auto"):
+            if mode == 64:
+                e.set_precision(64)
+            else:
+                e.set_precision_schedule(2 if mode == "schedule" else "auto")
+            gotm = e.from_mel_batch_f32(mels, x0, None)
+            refm = e.from_mel_batch([mm.astype(np.float64) for mm in mels], [x.astype(np.float64) for x in x0], None)
+            for a, r in zip(gotm, refm):
+                r32 = r.astype(np.float32)
+                assert a.dtype == np.float32
+                if mode == 64:
+                    assert np.array_equal(a, r32), (path, mode)                                   # one rounding of the same fp64 signal
+                else:                                                                              # (fused schedule: x + tail summed in fp32 resp. fp64 first)
+                    assert np.max(np.abs(a - r32)) <= 2 * float(np.spacing(np.abs(r32).max())), (path, mode)
+    e.set_path(0)
     e.set_precision(32)
     # the generic frame lengths take float host buffers too (their kernels are fp64 inside: the values are widened / narrowed once)
     for N, hop, K in ((1000, 250, 40), (6000, 1500, 96)):

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp32_start_mode")]   # these tests target the fp32 kernels unless they select a mode (conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RMS_TOL = 1e-4          # north_star: sample-for-sample within 1e-4 RMS
 

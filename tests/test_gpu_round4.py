@@ -1,0 +1,194 @@
+"""GPU tests added in round 4: what a caller gets WITHOUT a knob (the calibrated fp64-then-fp32 schedule, gomel_auto_fp64_iterations),
+calls in flight (gomel_from_mel_batch_submit / gomel_job_wait, whole-batch call mode).  (That a schedule's fp32 magnitudes -- narrowed
+from the fp64 rows since this round -- are the bits k_mel_to_mag<float> produces is held by test_gpu_round3.py::test_precision_schedule_is_fp64_then_fp32.)
+No fp32_start_mode fixture here: handles start as the library creates them."""
+import ctypes
+import math
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T = dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096)     # towav geometry (cmd/towav/main.go:30-37)
+S = dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024)        # BASELINE configs[3], the TTS geometry
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(a))))
+
+
+def mel_obj(fields, **kw):
+    import gomel_amd
+    m = gomel_amd.NewMel()
+    for k, v in dict(fields, **kw).items():
+        setattr(m, k, v)
+    return m
+
+
+def inputs(U, F, K, first=0):
+    mels = [np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
+    return mels, [1000 + first + u for u in range(U)]
+
+
+def run_batch(eng, mels, seeds):
+    import gomel_amd
+    b = gomel_amd.Batch(eng, [len(m) for m in mels])
+    b.upload(mels, None, seeds)
+    b.run()
+    out = b.download()
+    tm = b.run_timed()
+    b.close()
+    return out, tm
+
+
+@pytest.mark.parametrize("fields,iters", [(T, 60), (S, 60), (T, 10), (S, 2)])
+def test_the_default_call_is_the_calibrated_schedule(oracle, fields, iters, monkeypatch):
+    """A handle nobody touched runs gomel_auto_fp64_iterations(cfg, I) iterations in fp64 and the rest in fp32: the same BITS as the
+    explicit schedule of that k, launches split k : I - k between k_gl_fused_d and k_gl_fused; GOMEL_PRECISION picks another start
+    mode; gomel_set_precision(h, 0) / GOMEL_SCHEDULE_AUTO come back to it."""
+    import gomel_amd
+    from gomel_amd import _lib
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    m = mel_obj(fields, GriffinLimIterations=iters)
+    eng = m.engine()
+    k = _lib.lib().gomel_auto_fp64_iterations(ctypes.byref(eng.cfg), iters)
+    assert 0 < k <= iters and eng.fp64_iterations() == k and eng.fp64_iterations(iters) == k
+    K = fields["NumMels"]
+    mels, seeds = inputs(24, 200, K)
+    eng.set_path(2)
+    odef, tm = run_batch(eng, mels, seeds)
+    assert tm["iter_launches"] == iters and tm["iter64_launches"] == min(k, iters)
+    eng.set_precision_schedule(k)
+    osch, _ = run_batch(eng, mels, seeds)
+    assert all(np.array_equal(a, b) for a, b in zip(odef, osch))
+    eng.set_precision(32)
+    assert eng.fp64_iterations() == 0
+    o32, tm32 = run_batch(eng, mels, seeds)
+    assert tm32["iter64_launches"] == 0
+    eng.set_precision(64)
+    assert eng.fp64_iterations() == iters
+    o64, _ = run_batch(eng, mels, seeds)
+    for mode in (0, "auto"):
+        if mode == 0:
+            eng.set_precision(0)
+        else:
+            eng.set_precision(32); eng.set_precision_schedule("auto")
+        assert eng.fp64_iterations() == k
+        again, _ = run_batch(eng, mels, seeds)
+        assert all(np.array_equal(a, b) for a, b in zip(odef, again))
+    # the default sits between the two pure modes: (much) nearer to fp64 throughout than fp32 throughout is
+    edef = max(rms(a - b) for a, b in zip(odef, o64))
+    e32 = max(rms(a - b) for a, b in zip(o32, o64))
+    print("%s I=%d k=%d: default vs fp64 %.2e, fp32 vs fp64 %.2e" % (fields["Resolut"], iters, k, edef, e32))
+    assert edef < 3e-5 and edef <= e32
+    eng.close()
+    for env, want in (("32", 0), ("64", iters), ("auto", k)):
+        monkeypatch.setenv("GOMEL_PRECISION", env)
+        e2 = gomel_amd.Engine(m._config())
+        assert e2.fp64_iterations() == want
+        e2.close()
+
+
+def test_small_batches_run_fp64_throughout_under_the_default(oracle, coracle, monkeypatch):
+    """One utterance (the persistent kernel's size) and a handful (the generic kernels') never see an fp32 iteration under the default
+    schedule -- the schedule's hand-over exists on the fused kernels only: ~1e-12 from the oracle where the fp32 kernels sit at 1e-6."""
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    fields = dict(T, GriffinLimIterations=8)
+    m = mel_obj(fields)
+    cfg = oracle.MelConfig(**fields)
+    for frames in ([342], [700, 650, 40]):
+        mels = [oracle.random_logmel(f, 192, seed=f) for f in frames]
+        seeds = list(range(len(frames)))
+        got = m.engine().from_mel_batch(mels, None, seeds)
+        for g, mel, s in zip(got, mels, seeds):
+            want, _ = coracle.from_mel(cfg, mel, oracle.x0_splitmix(s, len(g)))
+            assert rms(g - want) < 1e-10
+
+
+@pytest.mark.parametrize("mode", ["default", 32, 64])
+def test_submitted_jobs_equal_the_whole_batch_bit_for_bit(oracle, mode, monkeypatch):
+    """gomel_from_mel_batch_submit / gomel_job_wait: two calls in flight on one handle (different inputs, different output buffers),
+    waited for out of order; each result equals the resident batch API's over the same utterances -- the same whole-batch launches --
+    bit for bit, and so does the synchronous call on a handle in whole-batch call mode (gomel_set_call_mode).  A call too small for
+    the fused kernels comes back as a finished job with the chunked call's result."""
+    import gomel_amd
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    fields = dict(T, GriffinLimIterations=12)
+    K, U, F = 192, 40, 200
+    m = mel_obj(fields)
+    eng = m.engine()
+    if mode != "default":
+        eng.set_precision(mode)
+    sets = [inputs(U, F, K, first=100 * i) for i in range(3)]
+    refs = [run_batch(eng, mels, seeds)[0] for mels, seeds in sets]
+    L = eng.out_len(F * K)
+    bound = []
+    for mels, _ in sets:
+        hm = [gomel_amd.host_alloc((F * K, 2)) for _ in range(U)]
+        for a, src in zip(hm, mels):
+            a[:] = src
+        ho = [gomel_amd.host_alloc(L) for _ in range(U)]
+        for o in ho:
+            o[:] = -1.0
+        bound.append(eng.bind_buffers(hm, ho))
+    jobs = [eng.submit_bound(bound[0], sets[0][1]), eng.submit_bound(bound[1], sets[1][1])]
+    got1 = [np.array(v) for v in jobs[1].wait()]                      # out of order
+    jobs.append(eng.submit_bound(bound[2], sets[2][1]))               # a third while the first is still unclaimed
+    got0 = [np.array(v) for v in jobs[0].wait()]
+    got2 = [np.array(v) for v in jobs[2].wait()]
+    assert jobs[0].done() and jobs[1].done()
+    for got, ref in zip((got0, got1, got2), refs):
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+    # pageable caller buffers (pinned by the library for the life of the job)
+    pm = [np.array(a) for a in sets[0][0]]
+    po = [np.zeros(L) for _ in range(U)]
+    j = eng.submit_bound(eng.bind_buffers(pm, po), sets[0][1])
+    assert all(np.array_equal(a, b) for a, b in zip(j.wait(), refs[0]))
+    # the synchronous call in whole-batch call mode: the same launches, the same bits; chunked mode: other segments, rounding level
+    eng.set_call_mode(1)
+    sync = eng.from_mel_batch(sets[1][0], None, sets[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(sync, refs[1]))
+    eng.set_call_mode(0)
+    # too small for the fused kernels: finished inside submit, the chunked call's result
+    small_m, small_s = inputs(2, 30, K, first=7)
+    sm = [np.array(a) for a in small_m]
+    so = [np.zeros(eng.out_len(30 * K)) for _ in range(2)]
+    js = eng.submit_bound(eng.bind_buffers(sm, so), small_s)
+    assert js.done()
+    want = eng.from_mel_batch(small_m, None, small_s)
+    assert all(np.array_equal(a, b) for a, b in zip(js.wait(), want))
+    # errors surface at submit, nothing is left in flight
+    with pytest.raises(gomel_amd.GomelError):
+        eng.submit_bound(eng.bind_buffers([np.zeros((191, 2))], [np.zeros(8192)]), [0])
+    eng.close()
+
+
+def test_two_threads_calling_in_whole_batch_mode_get_the_sequential_bits(oracle, monkeypatch):
+    """SURVEY 8(b) "handle usable from concurrent goroutines": two host threads call gomel_from_mel_batch in a loop on ONE handle in
+    whole-batch call mode -- their calls pipeline (copies of one beside the kernels of the other) -- and every result equals the
+    same call made alone, bit for bit."""
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    fields = dict(S, GriffinLimIterations=20)
+    K, U, F = 80, 96, 300
+    m = mel_obj(fields)
+    eng = m.engine()
+    eng.set_call_mode(1)
+    work = [inputs(U, F, K, first=1000 * i) for i in range(2)]
+    alone = [eng.from_mel_batch(mels, None, seeds) for mels, seeds in work]
+    errors = []
+
+    def loop(i):
+        try:
+            for _ in range(6):
+                got = eng.from_mel_batch(work[i][0], None, work[i][1])
+                if not all(np.array_equal(a, b) for a, b in zip(got, alone[i])):
+                    errors.append((i, "mismatch"))
+        except Exception as ex:                                       # noqa: BLE001 -- reported below
+            errors.append((i, repr(ex)))
+    ts = [threading.Thread(target=loop, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors[:3]
+    eng.close()

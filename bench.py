@@ -496,7 +496,7 @@ def main():
             if name == args.mode:
                 continue
             set_mode(name)
-            psteps = max(3, args.steps // 3)
+            psteps = max(3, args.steps)                               # as many as the headline: a pipeline's fill and drain (first upload, last download) weigh 1/steps
             el, _, _, outs_p = host_to_host(engine, fields, n_utt, frames, first, psteps, 1, lambda: None, depth=depth)
             el1, _, _, _ = host_to_host(engine, fields, n_utt, frames, first, 3, 1, lambda: None, depth=0)
             rfps, tmp = resident(engine, fields, min(n_utt, BLOCK), frames, first, 3)

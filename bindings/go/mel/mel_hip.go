@@ -66,14 +66,23 @@ func statusErr(rc C.int) error {
 
 // Fp64Iterations selects the arithmetic of the Griffin-Lim iterations for the calls that follow (not in the reference, whose
 // arithmetic is float64 throughout; the struct Mel stays field for field the reference's, so this is a package variable):
-// 0 = the fp32 kernels (fastest; on spectrograms that are not consistent ~1 % of the utterances end more than 1e-4 RMS from
-// the float64 result after 60 iterations), -1 = the fp64 kernels throughout (agrees with float64 arithmetic on every input),
-// k > 0 = the first k iterations in fp64, the rest in fp32 (C.gomel_set_precision_schedule; 30 keeps 60-iteration calls
-// within 1e-5 on everything measured).
-var Fp64Iterations = 0
+// Fp64Auto (the default) = the library's calibrated schedule, C.gomel_auto_fp64_iterations: the first k(GriffinLimIterations)
+// iterations in fp64, the rest in fp32 -- within 1e-4 RMS of the float64 result on every utterance of the calibration sets (35 of 60;
+// 1 of the reference's shipped 2); 0 = the fp32 kernels throughout (the fast mode; on spectrograms that are not consistent ~1 % of
+// 60-iteration utterances end more than 1e-4 RMS from the float64 result), -1 = the fp64 kernels throughout (agrees with float64
+// arithmetic on every input), k > 0 = the first k iterations in fp64, the rest in fp32 (C.gomel_set_precision_schedule).
+const Fp64Auto = math.MinInt32 // C.GOMEL_SCHEDULE_AUTO
+
+var Fp64Iterations = Fp64Auto
+
+// WholeBatchCalls = true makes every FromMelBatch call one whole batch on the device (C.gomel_set_call_mode(h, 1)) instead of a
+// chunked one: for programs that call FromMelBatch from two or more goroutines on the same configuration, whose calls then
+// pipeline -- the copies of one call beside the kernels of the other (INTEGRATION.md).  A lone caller leaves it false.
+var WholeBatchCalls = false
 
 type engineKey struct {
 	numMels, window, resolut, iters, fp64 int32
+	whole                                 bool
 	fmin, fmax, tuneMul, tuneAdd         float64
 }
 
@@ -93,7 +102,7 @@ var (
 )
 
 func (m *Mel) key() engineKey {
-	return engineKey{int32(m.NumMels), int32(m.Window), int32(m.Resolut), int32(m.GriffinLimIterations), int32(Fp64Iterations), m.MelFmin, m.MelFmax, m.TuneMul, m.TuneAdd}
+	return engineKey{int32(m.NumMels), int32(m.Window), int32(m.Resolut), int32(m.GriffinLimIterations), int32(Fp64Iterations), WholeBatchCalls, m.MelFmin, m.MelFmax, m.TuneMul, m.TuneAdd}
 }
 
 // acquire returns the handle for m's current field values, creating it on first use; release() must follow.
@@ -119,6 +128,12 @@ func (m *Mel) acquire() (*engine, error) {
 	if rc := C.gomel_set_precision_schedule(e.h, C.int32_t(k.fp64)); rc != C.GOMEL_OK {
 		C.gomel_destroy(e.h)
 		return nil, statusErr(rc)
+	}
+	if k.whole {
+		if rc := C.gomel_set_call_mode(e.h, 1); rc != C.GOMEL_OK {
+			C.gomel_destroy(e.h)
+			return nil, statusErr(rc)
+		}
 	}
 	engines[k] = e
 	for len(engines) > maxEngines { // evict idle handles, least recently used first

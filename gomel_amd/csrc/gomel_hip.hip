@@ -564,6 +564,7 @@ struct gomel_batch {
     int g_max = 0;
     // persistent path (k_gl_persist): d_yw holds its three output buffers, d_ctl = {err, pad[3]}
     int persist = 0;
+    int pmix_k = 0, pmix_occ = 0;   // > 0: precision schedule on the persistent path -- k_gl_persist_d for the first pmix_k iterations, then k_gl_persist<.., pmix_occ, ..> from its result
     int n_wg = 0;
     int err_slot = -1;
     int persist_units = 0;     // share of the device this batch's queued persistent launch is accounted with (persist_take)
@@ -1021,17 +1022,43 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             } else {
             if (persist) {   // 64-bit mode, a batch that fits the chip: every iteration in one launch (k_gl_persist_d), then x_I = overlap-add of the last frames
                 const size_t buf_doubles = (size_t)b->total_frames * N;
+                const int I64 = b->pmix_k ? b->pmix_k : I;          // precision schedule: the fp64 launch covers the first pmix_k iterations only
                 HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
                 HIPCHK(hipMemsetAsync(b->d_ywd, 0xff, buf_doubles * 8, s));
+                if (b->pmix_k) {   // the fp32 launch's magnitudes: the fp64 rows rounded once (as on the fused path); its exchange buffer starts as "not stored yet"
+                    const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
+                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
+                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
+                    HIPCHK(hipMemsetAsync(b->d_yw, 0xff, buf_doubles * 4, s));
+                }
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
                 GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
-                                                       b->d_ywd, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt));
+                                                       b->d_ywd, b->d_ctl, b->total_frames, I64, c.window, h->persist_ticks, h->persist_nap, h->dt));
+                if (b->pmix_k) {
+                    // x_k = the overlap-add of the fp64 launch's last frames (k_ola's order), rounded to fp32 once; then the remaining
+                    // iterations in the fp32 launch, and x_I = the overlap-add of ITS last frames.  A timeout in either launch sets the
+                    // same word: the host recomputes the whole batch with the per-iteration kernels.
+                    hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd + (size_t)((I64 - 1) % 3) * buf_doubles, b->d_xd[1], N, c.window);
+                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[1], b->d_x[0], b->total_len);
+#define GOMEL_PERSIST_LAUNCH(OCC, DEPTH)                                                                                                                     \
+    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, OCC, DEPTH>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, \
+                                           b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I - I64, c.window, h->persist_ticks, h->persist_nap, h->dt))
+                    if (b->pmix_occ == 2) { GOMEL_PERSIST_LAUNCH(2, 2); } else { GOMEL_PERSIST_LAUNCH(1, 4); }
+#undef GOMEL_PERSIST_LAUNCH
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
+                    const float* y_last = b->d_yw + (size_t)((I - I64 - 1) % 3) * buf_doubles;
+                    if (b->io32) hipLaunchKernelGGL(k_ola_out<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out32, N, c.window);
+                    else hipLaunchKernelGGL(k_ola_out<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, y_last, out64, N, c.window);
+                } else {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
                 // x_I = the overlap-add of the last iteration's frames (float host buffers: summed in fp64 into the idle second signal buffer, narrowed below)
                 hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd + (size_t)((I - 1) % 3) * buf_doubles, b->io32 ? b->d_xd[1] : out64, N, c.window);
                 if (b->io32) hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[1], out32, b->total_len);
+                }
             }
-            for (int it = 0; it < I && !persist; it++) {
+            const bool gmix = !persist && b->pmix_k > 0;           // precision schedule on the generic kernels (also the recomputation of a persistent launch that gave up: the same bits)
+            const int I64g = gmix ? b->pmix_k : I;
+            for (int it = 0; it < I64g && !persist; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
                 if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
                 if (h->generic)
@@ -1043,6 +1070,24 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
                 curd ^= 1;
             }
+            if (gmix) {   // hand-over: the fp32 magnitudes are the fp64 rows rounded once, the signal likewise; then the fp32 generic pair
+                const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
+                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[curd], b->d_x[0], b->total_len);
+                int cur = 0;
+                for (int it = I64g; it < I; it++) {
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
+                    GOMEL_DISPATCH_N(N, launch_frames<NN>(b, b->d_x[cur]));
+                    if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s));
+                    hipLaunchKernelGGL(k_ola<float>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_yw, b->d_x[cur ^ 1], N, c.window);
+                    cur ^= 1;
+                }
+                if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
+                const unsigned gf = (unsigned)std::min<int64_t>((b->total_len + 255) / 256, 65536);
+                if (b->io32) hipLaunchKernelGGL(k_finalize<float>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out32, b->total_len);
+                else hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
+            } else {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
             if (b->want_spec && h->generic)   // the literal form's clamp step on x_{I-1}, bins 0 ... N/2 (d_magd holds |spectrogram| as the caller gave it)
                 hipLaunchKernelGGL(glany::k_any_frames<glany::kAnySpec>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
@@ -1053,6 +1098,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             if (b->fast == 1) hipLaunchKernelGGL(k_add_tails_d, dim3((unsigned)b->segs.size()), dim3(256), 0, s, b->d_segs, b->d_taild[curd], b->d_xd[curd], N - c.window, c.window);
             if (!persist && b->io32) hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[curd], out32, b->total_len);
             else if (!persist) HIPCHK(hipMemcpyAsync(b->d_out, b->d_xd[curd], (size_t)b->total_len * 8, hipMemcpyDeviceToDevice, s));
+            }   // !gmix
             }   // !mixed_k
         } else {
         if (b->direct) launch_mag_direct<float>(N, b->total_frames, s, mel64, b->d_mag, b->d_nyq);
@@ -1122,7 +1168,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
         HIPCHK(hipEventElapsedTime(&tm->iter_ms, b->ev[1], b->ev[2]));
         tm->dom_ms = 0.f; tm->dom64_ms = 0.f;
-        const int n64 = persist ? 0 : b->mixed_k ? b->mixed_k : (b->precise && b->fast) ? I : 0;   // launches of the fp64 fused kernel among them
+        const int n64 = persist ? 0 : b->mixed_k ? b->mixed_k : (b->precise && b->fast) ? I : (b->precise && b->pmix_k) ? b->pmix_k : 0;   // launches of the fp64 kernel among them
         for (int it = 0; it < (persist ? std::min(I, 1) : I); it++) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, b->dom_ev[2 * it], b->dom_ev[2 * it + 1]));
@@ -1422,8 +1468,11 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         const bool room = h->batches_seen >= h->persist_retry_at && h->err_slab && !h->err_free.empty() && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20);
         if (room && !b->precise && n_wg <= persist_census(h, 2) && b->total_frames * (int64_t)N < ((int64_t)1 << 28))
             b->persist = n_wg <= persist_census(h, 1) ? 1 : 2;   // = the kernel's OCC: one wave per SIMD while the batch fits that way
-        else if (room && b->precise && n_wg <= persist_census(h, 3) && b->total_frames * (int64_t)N < ((int64_t)1 << 27))
+        else if (room && b->precise && n_wg <= persist_census(h, 3) && b->total_frames * (int64_t)N < ((int64_t)1 << 27)) {
             b->persist = 3;                                       // 64-bit mode: k_gl_persist_d (three buffers of doubles: < 2^32 bytes)
+            // a precision schedule on this path too (round 4): the fp64 launch for the first k64 iterations, the fp32 launch for the rest
+            if (k64 > 0 && k64 < I && n_wg <= persist_census(h, 2)) { b->pmix_k = k64; b->pmix_occ = n_wg <= persist_census(h, 1) ? 1 : 2; }
+        }
         if (b->persist) {
             b->n_wg = (int)n_wg;
             b->err_slot = h->err_free.back(); h->err_free.pop_back();
@@ -1433,9 +1482,10 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && kind &&
                (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? kind : 0;
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
-    // Precision schedule: only where it pays -- the fused kernel's batches.  Everything smaller (persistent / generic kernels: a
-    // handful of utterances) and the generic lengths stay fp64 for the whole call: correct, and cheap at that size.
+    // Precision schedule: on the fused kernel's batches and (pmix_k, above) on the persistent kernel's.  What the generic kernels take
+    // (a handful of utterances that fit neither) and the generic lengths stay fp64 for the whole call: correct, and cheap at that size.
     if (b->precise && !h->generic && b->fast && k64 > 0 && k64 < I) b->mixed_k = k64;
+    if (b->precise && !h->generic && !b->fast && !b->persist && !b->want_spec && k64 > 0 && k64 < I) { b->pmix_k = k64; b->pmix_occ = 0; }   // the generic pair: fp64 launches, then fp32 ones
     int rc = GOMEL_OK;
     const hipStream_t ist = init_stream ? init_stream : h->stream;
     auto alloc = [&](void** p, size_t bytes) { if (!rc && h->pool.alloc(p, bytes) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; } };
@@ -1474,6 +1524,13 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
                 b->ctl_bytes = 16;
                 alloc((void**)&b->d_ctl, b->ctl_bytes);
                 alloc((void**)&b->d_frame_utt, (size_t)b->total_frames * 4);
+            }
+            if (b->pmix_k) {   // the fp32 launches' buffers beside the fp64 ones (both signal buffers: a persistent launch that gives up is recomputed by the generic pair)
+                alloc((void**)&b->d_mag, (size_t)b->total_frames * (N / 2) * 4);
+                alloc((void**)&b->d_nyq, ((size_t)b->total_frames + 4) * 4);
+                alloc((void**)&b->d_x[0], (size_t)b->total_len * 4);
+                alloc((void**)&b->d_x[1], (size_t)b->total_len * 4);
+                alloc((void**)&b->d_yw, (size_t)b->total_frames * N * 4 * (b->persist ? 3 : 1));
             }
         }
     } else if (I > 0) {

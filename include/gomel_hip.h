@@ -231,8 +231,9 @@ int gomel_set_precision(gomel_handle* h, int bits);
  * throughout can end 1e-4 away from the reference's float64 arithmetic.
  *   GOMEL_SCHEDULE_AUTO = the calibrated schedule (= gomel_set_precision(h, 0), the default);
  *   0 = fp32 throughout (= gomel_set_precision(h, 32)); negative, or not below the call's iteration count = fp64 throughout (= 64).
- * A schedule applies to the batches the fused kernels take; smaller batches (one utterance, a handful) and the generic frame
- * lengths run fp64 throughout whenever the schedule asks for any fp64 iteration at all. */
+ * A schedule runs on every kernel path of the register FFT cores (fused, persistent, generic pair: a 64-bit call of k iterations
+ * followed by an fp32 call started from its output, bit for bit); the generic frame lengths (their kernels are fp64) and
+ * gomel_istft_spec run fp64 throughout whenever the schedule asks for any fp64 iteration at all. */
 #define GOMEL_SCHEDULE_AUTO (-2147483647 - 1)
 int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations);
 /* The automatic schedule: of a call of `iterations` Griffin-Lim iterations, how many run in fp64 first (0 = none: the reference's

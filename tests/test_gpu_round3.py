@@ -155,8 +155,8 @@ def test_towav_command_line(tmp_path, capsys):
 def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
     """gomel_set_precision_schedule(h, k): the first k iterations in fp64 (k_gl_fused_d), the signal handed over once (tails folded
     in, rounded to fp32), the remaining iterations in fp32 (k_gl_fused).  That is exactly: a 64-bit call of k iterations, then an
-    fp32 call of I - k iterations started from its output -- bit for bit.  Outside the fused kernel's batches (here: the same
-    batch on the generic kernels) a schedule runs fp64 throughout, and the degenerate schedules are the plain modes."""
+    fp32 call of I - k iterations started from its output -- bit for bit -- on the fused kernels, on the generic pair and (same bits as
+    the generic pair) on the persistent kernel; the degenerate schedules are the plain modes."""
     import gomel_amd
     I, k = 7, 3
     K = fields["NumMels"]
@@ -190,9 +190,21 @@ def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
     same, tms = run(I, I, 2)                                    # a schedule that covers every iteration is 64-bit mode
     assert tms["iter64_launches"] == I and all(np.array_equal(a, b) for a, b in zip(all64, same))
     gen64, _ = run(I, -1, 1)
-    gens, tmg = run(I, k, 1)                                    # generic kernels: no schedule, fp64 throughout
-    assert tmg["iter64_launches"] == 0 and tmg["fast_path"] == 0 and all(np.array_equal(a, b) for a, b in zip(gen64, gens))
     assert max(rms(a - b) for a, b in zip(gen64, all64)) < 1e-12
+    # the generic pair runs the same schedule (round 4): fp64 launches for k iterations, the hand-over, fp32 launches for the rest --
+    # again exactly the 64-bit call followed by the fp32 call; and the persistent kernel (where the geometry admits it), which sums
+    # the frames in the generic kernels' order, gives the generic pair's bits
+    gens, tmg = run(I, k, 1)
+    assert tmg["iter64_launches"] == k and tmg["fast_path"] == 0
+    g1, _ = run(k, -1, 1)
+    g2, _ = run(I - k, 0, 1, x0s=g1)
+    assert all(np.array_equal(a, b) for a, b in zip(gens, g2))
+    try:
+        pers, tmp = run(I, k, 3)
+    except gomel_amd.GomelError:
+        pers = None                                             # hop not a multiple of 4: the persistent kernel does not take it
+    if pers is not None:
+        assert tmp["fast_path"] == 2 and all(np.array_equal(a, b) for a, b in zip(pers, gens))
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]: one rank's shard

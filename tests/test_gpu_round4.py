@@ -91,20 +91,39 @@ def test_the_default_call_is_the_calibrated_schedule(oracle, fields, iters, monk
         e2.close()
 
 
-def test_small_batches_run_fp64_throughout_under_the_default(oracle, coracle, monkeypatch):
-    """One utterance (the persistent kernel's size) and a handful (the generic kernels') never see an fp32 iteration under the default
-    schedule -- the schedule's hand-over exists on the fused kernels only: ~1e-12 from the oracle where the fp32 kernels sit at 1e-6."""
+def test_small_batches_run_the_default_schedule_too(oracle, coracle, monkeypatch):
+    """One utterance (the persistent kernel's size) and a handful (the generic kernels') run the default schedule as the fused kernels
+    do (round 4): gomel_auto_fp64_iterations(cfg, I) iterations in the fp64 launch(es), the rest in the fp32 one(s).  The persistent
+    path gives the generic pair's bits; both are far inside the tolerance; a forced timeout of the persistent launch recomputes to
+    the same bits."""
+    import gomel_amd
     monkeypatch.delenv("GOMEL_PRECISION", raising=False)
     fields = dict(T, GriffinLimIterations=8)
-    m = mel_obj(fields)
     cfg = oracle.MelConfig(**fields)
     for frames in ([342], [700, 650, 40]):
         mels = [oracle.random_logmel(f, 192, seed=f) for f in frames]
         seeds = list(range(len(frames)))
-        got = m.engine().from_mel_batch(mels, None, seeds)
+        m = mel_obj(fields)
+        e = m.engine()
+        k = e.fp64_iterations()
+        assert 0 < k < 8
+        got, tm = run_batch(e, mels, seeds)
+        assert tm["fast_path"] == (2 if frames == [342] else 0) and (tm["fast_path"] == 2 or tm["iter64_launches"] == k)
+        e.set_path(1)
+        gen, tmg = run_batch(e, mels, seeds)
+        assert tmg["fast_path"] == 0 and tmg["iter64_launches"] == k
+        assert all(np.array_equal(a, b) for a, b in zip(got, gen))
         for g, mel, s in zip(got, mels, seeds):
             want, _ = coracle.from_mel(cfg, mel, oracle.x0_splitmix(s, len(g)))
-            assert rms(g - want) < 1e-10
+            assert rms(g - want) < 1e-5
+        e.close()
+        if frames == [342]:
+            monkeypatch.setenv("GOMEL_PERSIST_TICKS", "0")      # every wait of the persistent launches times out at once
+            e2 = mel_obj(fields).engine()
+            monkeypatch.delenv("GOMEL_PERSIST_TICKS")
+            redo = e2.from_mel_batch(mels, None, seeds)
+            assert all(np.array_equal(a, b) for a, b in zip(redo, gen))
+            e2.close()
 
 
 @pytest.mark.parametrize("mode", ["default", 32, 64])

@@ -110,8 +110,8 @@ def test_config3_full_size_every_utterance_against_the_oracle(oracle, coracle, m
 @pytest.mark.parametrize("mode", ["default", 32])
 def test_config2_full_size_single_utterance_automatic_path(oracle, coracle, monkeypatch, mode):
     """BASELINE configs[1]: one 10 s utterance @44.1 kHz (342 frames of the survey's chirp + AM tone + noise through ToMel), 60
-    iterations, the path the library picks by itself for a batch of this size -- as a caller gets it without a knob (a batch this
-    small runs fp64 throughout under the default schedule), and in the fp32 fast mode."""
+    iterations, the path the library picks by itself for a batch of this size -- as a caller gets it without a knob (the default
+    schedule on the persistent kernel), and in the fp32 fast mode."""
     fields = dict(T, GriffinLimIterations=60)
     if mode == "default":
         monkeypatch.delenv("GOMEL_PRECISION", raising=False)
@@ -126,7 +126,7 @@ def test_config2_full_size_single_utterance_automatic_path(oracle, coracle, monk
     got = m.FromMel(mel.copy(), x0=x0)
     want, _ = coracle.from_mel(cfg, mel, x0)
     print("config 2 (342 frames x 60 iterations), %s vs oracle: %.2e (signal rms %.3f)" % (mode, rms(got - want), rms(want)))
-    assert rms(got - want) < (1e-8 if mode == "default" else RMS_TOL)
+    assert rms(got - want) < (1e-5 if mode == "default" else RMS_TOL)      # (the default runs its schedule on the persistent kernel: 35 fp64 + 25 fp32 iterations)
 
 
 def test_config4_full_size_tts_batch(oracle, coracle, monkeypatch):

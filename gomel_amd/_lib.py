@@ -6,7 +6,7 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgomel_hip.so")
+LIB_PATH = os.environ.get("GOMEL_LIB") or os.path.join(HERE, "libgomel_hip.so")   # GOMEL_LIB: another build of the library (A/B timing, sanitizer builds)
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_float_p = ctypes.POINTER(ctypes.c_float)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -63,6 +64,9 @@ static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
 // per utterance: freed buffers are kept and handed out again to requests of similar size.  Guarded by the handle's mutex.
 struct DevPool {
     struct Block { void* p; size_t bytes; bool used; uint64_t stamp; };
+    // the allocator behind the cache: the HIP runtime in the product; gomel_debug_pool_selftest (CPU, sanitizer builds) injects host malloc
+    hipError_t (*alloc_fn)(void**, size_t) = [](void** q, size_t n) { return hipMalloc(q, n); };
+    hipError_t (*free_fn)(void*) = [](void* q) { return hipFree(q); };
     std::vector<Block> blocks;
     size_t cached = 0, cap = (size_t)16 << 30;  // bytes kept while unused (GOMEL_POOL_MB; 0 = no caching); the device has 288 GB
     uint64_t clock = 0;
@@ -74,15 +78,15 @@ struct DevPool {
             if (!k.used && k.bytes >= bytes && k.bytes <= bytes + bytes / 2 + 65536 && (best < 0 || k.bytes < blocks[best].bytes)) best = (int)i;
         }
         if (best >= 0) { blocks[best].used = true; cached -= blocks[best].bytes; *out = blocks[best].p; return hipSuccess; }
-        hipError_t e = hipMalloc(out, bytes);
-        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = hipMalloc(out, bytes); }   // give the cache back and retry
+        hipError_t e = alloc_fn(out, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = alloc_fn(out, bytes); }   // give the cache back and retry
         if (e == hipSuccess) blocks.push_back(Block{*out, bytes, true, 0});
         return e;
     }
     void release(void* p) {
         for (Block& k : blocks)
             if (k.p == p) { k.used = false; k.stamp = ++clock; cached += k.bytes; trim(cap); return; }
-        (void)hipFree(p);   // not ours (never happens): plain free
+        (void)free_fn(p);   // not ours (never happens): plain free
     }
     void trim(size_t keep) {   // drop the least recently released buffers until at most `keep` bytes stay cached
         while (cached > keep) {
@@ -90,13 +94,13 @@ struct DevPool {
             for (size_t i = 0; i < blocks.size(); i++)
                 if (!blocks[i].used && (old < 0 || blocks[i].stamp < blocks[old].stamp)) old = (int)i;
             if (old < 0) break;
-            (void)hipFree(blocks[old].p);
+            (void)free_fn(blocks[old].p);
             cached -= blocks[old].bytes;
             blocks.erase(blocks.begin() + old);
         }
     }
     void clear() {
-        for (Block& k : blocks) (void)hipFree(k.p);
+        for (Block& k : blocks) (void)free_fn(k.p);
         blocks.clear(); cached = 0;
     }
 };
@@ -441,8 +445,37 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
 // registration (range pinned by somebody else, partial overlap, memory that cannot be locked, ...) leaves that buffer pageable:
 // the runtime then stages the copy itself.  gomel_host_register / gomel_host_alloc (below) let a caller that reuses its
 // buffers pay the registration once instead of per call.
+// What the registry asks of the runtime.  The product's backend is HIP; gomel_debug_pin_backend(1) swaps in an in-process fake that
+// records registrations and counts contract violations (overlapping registrations, unregistering what is not registered), so that the
+// interval logic and its locking can be exercised -- under AddressSanitizer / ThreadSanitizer -- on a machine without a GPU.
+struct PinBackend {
+    bool (*foreign)(void* p, uintptr_t* base, size_t* size);   // pinned / device memory somebody else owns?  (its allocation's extent)
+    bool (*reg)(void* p, size_t bytes);
+    void (*unreg)(void* p);
+};
+static bool hip_pin_foreign(void* p, uintptr_t* base, size_t* size) {
+    hipPointerAttribute_t at;
+    *base = 0; *size = 0;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) {      // device / pinned by the caller
+        hipDeviceptr_t b = nullptr; size_t n = 0;
+        if (hipMemGetAddressRange(&b, &n, (hipDeviceptr_t)p) == hipSuccess && b && n) { *base = (uintptr_t)b; *size = n; }
+        (void)hipGetLastError();
+        return true;
+    }
+    (void)hipGetLastError();
+    return false;
+}
+static bool hip_pin_reg(void* p, size_t bytes) {
+    const bool ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
+    return ok;
+}
+static void hip_pin_unreg(void* p) { (void)hipHostUnregister(p); (void)hipGetLastError(); }
+static const PinBackend kHipPins = {hip_pin_foreign, hip_pin_reg, hip_pin_unreg};
+
 struct PinRegistry {
     struct Entry { size_t bytes; int users; };
+    const PinBackend* be = &kHipPins;
     std::mutex mu;
     std::map<uintptr_t, Entry> live;   // base -> extent, users
     // Ranges found pinned (or device memory) by somebody else -- gomel_host_alloc / hipHostMalloc buffers a bulk caller reuses.
@@ -465,20 +498,15 @@ struct PinRegistry {
             auto f = foreign.upper_bound(a);
             if (f != foreign.begin()) { auto pf = std::prev(f); if (a + bytes <= pf->first + pf->second) return 0; }
         }
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type != hipMemoryTypeUnregistered) {      // device / pinned by the caller
-            hipDeviceptr_t base = nullptr; size_t size = 0;
-            if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && base && size) {
+        uintptr_t fbase = 0; size_t fsize = 0;
+        if (be->foreign(p, &fbase, &fsize)) {
+            if (fbase && fsize) {
                 if (foreign.size() > 65536) foreign.clear();
-                foreign[(uintptr_t)base] = size;
+                foreign[fbase] = fsize;
             }
-            (void)hipGetLastError();
             return 0;
         }
-        (void)hipGetLastError();
-        const bool ok = hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();   // a refusal must not linger as the thread's "last error" (launches are checked with it)
-        if (!ok) return 0;
+        if (!be->reg(p, bytes)) return 0;
         live.emplace(a, Entry{bytes, 1});
         return a;
     }
@@ -487,8 +515,7 @@ struct PinRegistry {
         auto it = live.find(base);
         if (it == live.end()) return;
         if (--it->second.users == 0) {
-            (void)hipHostUnregister((void*)base);
-            (void)hipGetLastError();
+            be->unreg((void*)base);
             live.erase(it);
         }
     }
@@ -2337,6 +2364,94 @@ int gomel_debug_persist_state(gomel_handle* h, long long set_ticks, unsigned* ba
     if (backoff) *backoff = h->persist_backoff;
     if (paused_for) *paused_for = h->persist_retry_at > h->batches_seen ? h->persist_retry_at - h->batches_seen : 0;
     return GOMEL_OK;
+}
+// ---- diagnostics for the host-side logic (not in the header; tests/host_stress.cpp and the sanitizer runs reach them by name) ----
+// A fake pin backend: registrations live in a map of its own; overlapping registrations and unknown unregistrations are VIOLATIONS of
+// what the registry promises the runtime.
+static std::mutex g_fake_mu;
+static std::map<uintptr_t, size_t> g_fake_regs;
+static std::atomic<long> g_fake_violations{0}, g_fake_calls{0};
+static bool fake_pin_foreign(void*, uintptr_t* base, size_t* size) { *base = 0; *size = 0; return false; }
+static bool fake_pin_reg(void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
+    g_fake_calls++;
+    const uintptr_t a = (uintptr_t)p;
+    auto it = g_fake_regs.upper_bound(a);
+    if (it != g_fake_regs.begin()) { auto pr = std::prev(it); if (a < pr->first + pr->second) { g_fake_violations++; return false; } }
+    if (it != g_fake_regs.end() && it->first < a + bytes) { g_fake_violations++; return false; }
+    g_fake_regs[a] = bytes;
+    return true;
+}
+static void fake_pin_unreg(void* p) {
+    std::lock_guard<std::mutex> lk(g_fake_mu);
+    g_fake_calls++;
+    if (g_fake_regs.erase((uintptr_t)p) != 1) g_fake_violations++;
+}
+static const PinBackend kFakePins = {fake_pin_foreign, fake_pin_reg, fake_pin_unreg};
+int gomel_debug_pin_backend(int fake) {   // only while nothing is registered
+    std::lock_guard<std::mutex> lk(g_pins.mu);
+    if (!g_pins.live.empty()) return GOMEL_ERR_BAD_CONFIG;
+    g_pins.be = fake ? &kFakePins : &kHipPins;
+    g_pins.foreign.clear();
+    return GOMEL_OK;
+}
+int gomel_debug_pin_stats(long* live_registry, long* live_backend, long* violations, long* backend_calls) {
+    { std::lock_guard<std::mutex> lk(g_pins.mu); if (live_registry) *live_registry = (long)g_pins.live.size(); }
+    { std::lock_guard<std::mutex> lk(g_fake_mu); if (live_backend) *live_backend = (long)g_fake_regs.size(); }
+    if (violations) *violations = g_fake_violations.load();
+    if (backend_calls) *backend_calls = g_fake_calls.load();
+    return GOMEL_OK;
+}
+// The per-call pin scope (PinnedScope: want / commit / release at scope exit) on caller buffers, as gomel_from_mel_batch uses it --
+// without the copies: lets threads hammer the registry with aliased and nested ranges.
+int gomel_debug_pin_scope(void* const* ptrs, const size_t* bytes, size_t n, int hold_us) {
+    GOMEL_TRY
+    PinnedScope pins;
+    for (size_t i = 0; i < n; i++) pins.want(ptrs[i], bytes[i]);
+    pins.commit();
+    if (hold_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(hold_us));
+    return (int)pins.held.size();
+    GOMEL_CATCH
+}
+// The device-buffer cache against host malloc: random allocate / release / trim sequences with its invariants checked
+// (`cached` = the bytes of the unused blocks; a released block is handed out again or freed exactly once; clear() leaves nothing).
+// Returns the number of violated invariants.
+static thread_local long g_selftest_live = 0;   // (per thread: several self-tests may run at once)
+int gomel_debug_pool_selftest(unsigned seed, int iters) {
+    GOMEL_TRY
+    DevPool pool;
+    pool.alloc_fn = [](void** q, size_t n) { *q = malloc(n); if (*q) g_selftest_live++; return *q ? hipSuccess : hipErrorOutOfMemory; };
+    pool.free_fn = [](void* q) { free(q); g_selftest_live--; return hipSuccess; };
+    pool.cap = (size_t)8 << 20;
+    const long live0 = g_selftest_live;
+    std::vector<std::pair<void*, size_t>> held;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    int bad = 0;
+    for (int i = 0; i < iters; i++) {
+        const uint64_t r = rnd();
+        if (held.size() < 24 && (r & 3) != 0) {
+            void* p = nullptr;
+            const size_t n = (size_t)1 << (8 + r % 13);
+            if (pool.alloc(&p, n + (r >> 20) % 4096) != hipSuccess || !p) { bad++; continue; }
+            memset(p, 0xa5, 64);                                    // the block is really ours (ASan would object otherwise)
+            for (auto& h : held) if (h.first == p) bad++;            // handed out twice
+            held.emplace_back(p, n);
+        } else if (!held.empty()) {
+            const size_t k = r % held.size();
+            pool.release(held[k].first);
+            held.erase(held.begin() + k);
+        }
+        size_t unused = 0;
+        for (const DevPool::Block& b : pool.blocks) if (!b.used) unused += b.bytes;
+        if (unused != pool.cached || pool.cached > pool.cap) bad++;
+        if ((r & 1023) == 0) { pool.trim(0); if (pool.cached != 0) bad++; }
+    }
+    for (auto& h : held) pool.release(h.first);
+    pool.clear();
+    if (g_selftest_live != live0) bad++;
+    return bad;
+    GOMEL_CATCH
 }
 #ifdef GOMEL_STAMPS   // diagnostic build only: read (and clear) the per-phase cycle sums of k_gl_fused
 int gomel_debug_stamps(unsigned long long* out21, int clear) {

@@ -211,3 +211,37 @@ def test_two_threads_calling_in_whole_batch_mode_get_the_sequential_bits(oracle,
     for t in ts: t.join()
     assert not errors, errors[:3]
     eng.close()
+
+
+def test_tomel_command_line(oracle, tmp_path, capsys):
+    """`python -m gomel_amd.tomel <name | name.wav | name.flac>` = cmd/tomel/main.go:10-61: fixed towav-geometry parameters, the PNG
+    beside the input, `.wav` / base-name / `.flac` dispatch, the usage line and the error line with exit code 1; and the PNG it writes
+    goes back through `python -m gomel_amd.towav` (the reference's two CLIs are each other's inverse up to Griffin-Lim)."""
+    import os
+    import sys
+    import gomel_amd
+    from gomel_amd import codec, tomel, towav
+    sig = oracle.config2_signal(seconds=1.5)
+    wav = str(tmp_path / "a.wav")
+    gomel_amd.SaveWav(wav, sig, 44100)
+    assert tomel.main(["tomel", wav]) == 0 and os.path.exists(wav + ".png")
+    assert tomel.main(["tomel", str(tmp_path / "a")]) == 0 and os.path.exists(str(tmp_path / "a.png"))       # base name: <name>.wav -> <name>.png
+    assert open(wav + ".png", "rb").read() == open(str(tmp_path / "a.png"), "rb").read()
+    buf, samples, sr = codec.loadpng(wav + ".png", True)
+    m = gomel_amd.NewMel()
+    m.MelFmax, m.Window, m.NumMels, m.Resolut = 16000, 1280, 192, 4096
+    want = m.ToMel(codec.loadwav(wav)[0])
+    assert len(buf) == len(want) and float(sr) == float(np.float16(44100.0)) and abs(int(samples) - len(sig)) <= len(sig) // 100            # float16 metadata: < 1 % off
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import flac_writer as fw
+    pcm = np.round(sig * 20000).astype(np.int64).tolist()
+    frames = [fw.frame([pcm[i:i + 4096]], 16, k, "independent", [dict(kind="fixed", order=2, porder=3 if len(pcm[i:i + 4096]) % 8 == 0 else 0)])
+              for k, i in enumerate(range(0, len(pcm), 4096))]
+    fl = str(tmp_path / "b.flac")
+    open(fl, "wb").write(fw.stream(frames, 44100, 1, 16, len(pcm)))
+    assert tomel.main(["tomel", fl]) == 0 and os.path.exists(fl + ".png")
+    assert len(codec.loadpng(fl + ".png", True)[0]) == len(want)
+    assert tomel.main(["tomel"]) == 1 and "Usage" in capsys.readouterr().out
+    assert tomel.main(["tomel", str(tmp_path / "missing")]) == 1
+    assert "Error generating mel spectrogram: wavNotLoaded" in capsys.readouterr().out
+    assert towav.main(["towav", wav + ".png"]) == 0 and os.path.exists(wav + ".png.wav")

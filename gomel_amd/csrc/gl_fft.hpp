@@ -311,6 +311,20 @@ template <class S> GL_DEV void sync_reads_done(S& s) { if constexpr (IsSplitSync
 template <class S> GL_DEV void sync_before_write(S& s) { if constexpr (IsSplitSync<S>::value) s.wait(); }
 
 
+// Write bursts interleaved with arithmetic (fp64 kernel with split-phase synchronisation only, one wave per SIMD): sixteen
+// ds_write_b128 back to back fill the LDS FIFOs (SQ_LDS_DATA_FIFO_FULL + CMD_FIFO_FULL: 7 % of the wave cycles) while the vector unit
+// idles; issued one by one between the twiddle multiplies / the last butterfly stage they drain as fast as they come.  The wait for the
+// partner's reads moves in front of that arithmetic (where the compiler had hoisted it anyway).  GL_D_INTERLEAVE=0 builds the burst form.
+#ifndef GL_D_INTERLEAVE
+#define GL_D_INTERLEAVE 1
+#endif
+#define GL_SGB_VALU 0x002
+#define GL_SGB_DSW 0x200
+template <int NV, int NW> GL_DEV void sgb_valu_then_write() {   // NW times: NV vector instructions, one LDS write
+#pragma unroll
+    for (int i = 0; i < NW; i++) { __builtin_amdgcn_sched_group_barrier(GL_SGB_VALU, NV, 0); __builtin_amdgcn_sched_group_barrier(GL_SGB_DSW, 1, 0); }
+}
+
 // ---------------------------------------------------------------------------------------------- forward
 // In: v[j] = z[t + T*j].  Out: v[0..7] = Z[bA + B3*r], v[8..15] = Z[bB + B3*r] with bA = t, bB = (t ? B3 - t : B3/2).
 // `lds` is this stream's exchange area (G::LDS_SLOTS slots).  SYNC() is a barrier covering the stream's lanes.
@@ -326,6 +340,20 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<false, G::R1, G::NB1>(&v[u]);
     __builtin_amdgcn_sched_barrier(0);   // keep the twiddle reads above the butterfly: they land while it computes
+    constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
+    if constexpr (ILV) {
+        sync_before_write(sync);
+#pragma unroll
+        for (int u = 0; u < G::NB1; u++) {
+            const int t1 = t + G::T * u;
+#pragma unroll
+            for (int q = 0; q < G::R1; q++) {
+                if (q) v[u + G::NB1 * q] = cmul(v[u + G::NB1 * q], w1[u + G::NB1 * q]);
+                lds[q * G::SA + t1] = v[u + G::NB1 * q];
+            }
+        }
+        sgb_valu_then_write<4, 16>();
+    } else {
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) apply_tw<false, G::NB1, G::R1>(&v[u], &w1[u]);
     st.mark(0);
@@ -335,6 +363,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
         const int t1 = t + G::T * u;
 #pragma unroll
         for (int q = 0; q < G::R1; q++) lds[q * G::SA + t1] = v[u + G::NB1 * q];
+    }
     }
     sync();
     st.mark(1);
@@ -357,6 +386,19 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) dftR<false, G::R2, 1>(&v[u * G::R2]);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ILV) {
+        sync_before_write(sync);
+#pragma unroll
+        for (int u = 0; u < G::NB2; u++) {
+            const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
+#pragma unroll
+            for (int q = 0; q < G::R2; q++) {
+                if (q) v[u * G::R2 + q] = cmul(v[u * G::R2 + q], w2[u * G::R2 + q]);
+                lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
+            }
+        }
+        sgb_valu_then_write<4, 16>();
+    } else {
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
     st.mark(3);
@@ -366,6 +408,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
 #pragma unroll
         for (int q = 0; q < G::R2; q++) lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
+    }
     }
     sync();
     st.mark(4);
@@ -387,12 +430,26 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
 // kernel whose next step is a forward FFT can hand them to it instead of reading the table again.
 template <class G, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st, V* w1_out = nullptr) {
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
+    constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
+    if constexpr (ILV) {   // the first butterfly's eight outputs leave while the second one computes
+        sync_before_write(sync);
+        dft8<true, 1>(&v[0]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds[r * G::SB + bA] = v[r];
+        dft8<true, 1>(&v[8]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds[r * G::SB + bB] = v[8 + r];
+        __builtin_amdgcn_sched_group_barrier(GL_SGB_VALU, 56, 0);
+        sgb_valu_then_write<7, 8>();
+        sgb_valu_then_write<0, 8>();
+    } else {
     dft8<true, 1>(&v[0]);
     dft8<true, 1>(&v[8]);
     st.mark(8);
     sync_before_write(sync);
 #pragma unroll
     for (int r = 0; r < 8; r++) { lds[r * G::SB + bA] = v[r]; lds[r * G::SB + bB] = v[8 + r]; }
+    }
     sync();
     st.mark(9);
 #pragma unroll

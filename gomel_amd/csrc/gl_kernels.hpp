@@ -436,6 +436,9 @@ template <bool WIDE> struct StreamFlagSync {
 };
 
 constexpr int kFusedThreads = 256;
+#ifndef GL_WIN_B128
+#define GL_WIN_B128 0
+#endif
 // The workgroup's tables (pass-1 / pass-2 twiddles, window) from global memory into LDS: 16 bytes per lane and instruction, EVERY load
 // issued before the first LDS write, so the fill costs one memory round trip (the element-wise loops it replaces went out in batches
 // of five 8-byte loads, each batch waited for).  A chunk-sized launch of a host-to-host call pays this once per 12.5 frames: -1 % on
@@ -894,6 +897,19 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     v2f* tw1_l = lds + STREAMS * G::LDS_SLOTS;
     v2f* tw2_l = tw1_l + G::TW1_N;
     v2f* win_l = tw2_l + G::TW2_N;
+    // WPAIR (experiment GL_WIN_B128): the window table in LDS as ROW PAIRS -- entry jp * T + t = {w[2jp][t], w[2jp+1][t]}, 16 bytes -- so that the
+    // one-read-per-frame form fetches its 16 window pairs with 8 ds_read_b128 instead of 16 ds_read_b64 (same bytes, half the LDS instructions)
+    constexpr bool WPAIR = GL_WIN_B128 && fused_one_window_read(N, SH) && (STREAMS * G::LDS_SLOTS + G::TW1_N + G::TW2_N) % 2 == 0;
+    if constexpr (WPAIR) {
+        for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1[i];
+        for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2[i];
+        const v2f* wsrc = reinterpret_cast<const v2f*>(tb.window);
+        for (int i = threadIdx.x; i < G::C / 2; i += kFusedThreads) {
+            const int jp = i / T, tt = i % T;
+            const v2f a = wsrc[T * (2 * jp) + tt], b = wsrc[T * (2 * jp + 1) + tt];
+            reinterpret_cast<v4f*>(win_l)[i] = v4f{a.x, a.y, b.x, b.y};
+        }
+    } else
     fill_tables_lds<(STREAMS * G::LDS_SLOTS) % 2 == 0 && N >= 2048, G::TW1_N, G::TW2_N, G::C>(tw1_l, tw2_l, win_l, tb.tw1, tb.tw2, reinterpret_cast<const v2f*>(tb.window));
     __syncthreads();
     // this lane's pass-2 twiddles depend on the lane only: registers for the whole segment instead of 30 LDS reads per frame
@@ -1007,10 +1023,19 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     // 16 KB of the ~158 KB a frame moves through the LDS: the kernel is power-limited and LDS bytes are part of the bill).
     // (ROT: where the register file takes it without spilling -- fused_one_window_read; the other instantiations read the window twice)
     constexpr bool ROT = fused_one_window_read(N, SH);
+    const v4f* wl4 = reinterpret_cast<const v4f*>(win_l) + t;   // WPAIR: rows 2jp, 2jp+1 of this lane: wl4[T * jp]
+    auto load_window = [&](v2f (&w_)[16]) {
+        if constexpr (WPAIR) {
+#pragma unroll
+            for (int jp = 0; jp < 8; jp++) { const v4f q = wl4[T * jp]; w_[2 * jp] = v2f{q.x, q.y}; w_[2 * jp + 1] = v2f{q.z, q.w}; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) w_[j] = wl[T * j];
+        }
+    };
     v2f v[16];
     if constexpr (ROT) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = wl[T * j];
+        load_window(v);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= xin[j];
@@ -1090,8 +1115,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         st.mark(18);
         v2f w[16];   // the window: all 16 reads go out back to back (one LDS round trip, not sixteen)
         if constexpr (ROT) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) w[j] = wl[T * j];
+            load_window(w);
             __builtin_amdgcn_sched_barrier(0);
         }
         auto W = [&](int j) { if constexpr (ROT) return w[j]; else return wl[T * j]; };

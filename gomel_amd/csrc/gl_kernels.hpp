@@ -14,6 +14,7 @@
 
 #include "gl_fft.hpp"
 #include "gl_any.hpp"
+#include "gl_big.hpp"
 
 using namespace glfft;
 
@@ -27,6 +28,7 @@ struct BinRow {  // one linear bin of undomel (or one mel band of domel): data-i
 
 struct DevTables {
     glany::AnyTables any;  // generic-length path (gl_any.hpp); any.M == 0 when the register cores cover Resolut
+    glbig::BigTables big;  // frame lengths above 8192 (gl_big.hpp): big.Mc != 0; `any` then describes the 8192-point LDS transform
     const float* window;   // [N]
     const v2f* tw1;        // fp32 twiddles (Griffin-Lim)
     const v2f* tw2;
@@ -49,11 +51,13 @@ struct DevTables {
         default:   { constexpr int NN = 256;  __VA_ARGS__; } break; \
     }
 static inline bool gomel_supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-// what gl_any.hpp covers besides: every other length (odd ones too) up to 8192 (radix-2; Bluestein, above 4096 in its split form)
+// what gl_any.hpp covers besides: every other length (odd ones too) up to 8192 (radix-2; Bluestein, above 4096 in its split form);
+// gl_big.hpp: 8193 ... 65536 (Bluestein through HBM)
 static inline bool gomel_generic_n(int n) {
     if (n < 4 || gomel_supported_n(n)) return false;
-    return n <= 8192;
+    return n <= glbig::kMaxN;
 }
+static inline bool gomel_big_n(int n) { return n > 8192 && n <= glbig::kMaxN; }
 
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
     if (r.mode == 0) return e[r.lo];
@@ -1813,19 +1817,23 @@ __global__ __launch_bounds__(128) void k_stft_mag(const double* __restrict__ wav
 // domel (mel/impl.go:310-345) + spectral_normalize (mel/impl.go:410-419): one block per frame.  The frame's N/2+1 magnitudes are
 // staged in LDS with coalesced loads first (a band's row walks a run of bins: straight from global memory every thread strode
 // through its own run -- 1.0 TB/s; from LDS the kernel is bound by the 16 KB it reads and the 3 KB it writes per frame).
+// (staged = 0: frame lengths above 8192, whose magnitudes outgrow the default LDS allowance, read them from global memory)
 __global__ __launch_bounds__(256) void k_domel_log(const double* __restrict__ smag, const BinRow* __restrict__ dom, double* __restrict__ out,
-                                                   int K, int H) {
+                                                   int K, int H, int staged = 1) {
     extern __shared__ double m_sh[];                      // [H + 1]
     const int64_t f = blockIdx.x;
     const double* m = smag + f * (H + 1);
-    for (int k = threadIdx.x; k <= H; k += blockDim.x) m_sh[k] = m[k];
-    __syncthreads();
+    if (staged) {
+        for (int k = threadIdx.x; k <= H; k += blockDim.x) m_sh[k] = m[k];
+        __syncthreads();
+    }
+    const double* src = staged ? m_sh : m;
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         const BinRow r = dom[i];
         double2 o;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            double v = apply_row(r, m_sh + c);  // channel 1 is the same spectrum one bin up: |S[N-1-j]| = |S[j+1]|
+            double v = apply_row(r, src + c);  // channel 1 is the same spectrum one bin up: |S[N-1-j]| = |S[j+1]|
             if (v < 1e-5) v = 1e-5;
             (c ? o.y : o.x) = log(v);
         }

@@ -123,6 +123,7 @@ struct gomel_handle {
     int precise_iters = -1;       // kPrecSchedule: iterations in fp64 before the fp32 kernels take over
     int dom_status = GOMEL_OK;    // GOMEL_ERR_TABLE_RANGE when domel would index past the bins (the reference panics in ToMel)
     bool generic = false;         // Resolut outside the register FFT cores: gl_any.hpp kernels (fp64, any batch size)
+    bool big = false;             // ... above 8192: gl_big.hpp (every DFT a Bluestein convolution through HBM)
     // persistent small-batch kernel (k_gl_persist): resident-workgroup census, sticky off switch after a timeout, and a pinned
     // slab of timeout words (one per live batch: the kernel's *err comes down with the waveforms, no extra round trip)
     int persist_census[3] = {-1, -1, -1};   // workgroups of k_gl_persist<Resolut, 1 | 2> / k_gl_persist_d<Resolut> the device holds at once (-1: not asked yet)
@@ -279,7 +280,87 @@ template <class V> static void fill_twiddles(int N, int R1, int R2, std::vector<
 
 // Tables of the generic-length path: window (fp64 + fp32), mel rows, radix-2 twiddles of the M-point transform and, when N is
 // not a power of two, Bluestein's chirp and the transform of its filter (fp64 on the host, in the order fft_dif leaves its output).
+// Frame lengths above 8192 (gl_big.hpp): window, mel rows, the twiddles of the 8192-point LDS transform, Bluestein's chirp and the
+// transform of its filter over Mc >= 2N-1 points -- in NATURAL order and pre-divided by Mc (fp64 on the host).
+static int upload_tables_big(gomel_handle* h) {
+    const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
+    int Mc = glbig::kSub * 4, logMc = glbig::kLogSub + 2;
+    while (Mc < 2 * N - 1) { Mc <<= 1; logMc++; }
+    std::vector<v2d> tw((size_t)glbig::kSub / 2), chirp((size_t)N), b((size_t)Mc, v2d{0.0, 0.0}), twc((size_t)Mc / 2), bhat((size_t)Mc);
+    for (int j = 0; j < glbig::kSub / 2; j++) { const double a = -2.0 * M_PI * (double)j / (double)glbig::kSub; tw[j] = v2d{std::cos(a), std::sin(a)}; }
+    for (int j = 0; j < Mc / 2; j++) { const double a = -2.0 * M_PI * (double)j / (double)Mc; twc[j] = v2d{std::cos(a), std::sin(a)}; }
+    auto w = [&](int64_t n) { const double a = -M_PI * (double)((n * n) % (2 * (int64_t)N)) / (double)N; return v2d{std::cos(a), std::sin(a)}; };   // e^{-i pi n^2 / N}
+    for (int n = 0; n < N; n++) { chirp[n] = w(n); b[n] = v2d{chirp[n].x, -chirp[n].y}; if (n) b[Mc - n] = b[n]; }
+    for (int s = 0; s < logMc; s++) {   // FFT_Mc of b, decimation in frequency: bit-reversed order out
+        const int half = Mc >> (s + 1);
+        for (int idx = 0; idx < Mc / 2; idx++) {
+            const int grp = idx >> (logMc - 1 - s), pos = idx & (half - 1), i0 = (grp << (logMc - s)) + pos, i1 = i0 + half;
+            const v2d a = b[i0], c = b[i1], t = twc[(size_t)pos << s], d = v2d{a.x - c.x, a.y - c.y};
+            b[i0] = v2d{a.x + c.x, a.y + c.y};
+            b[i1] = v2d{d.x * t.x - d.y * t.y, d.x * t.y + d.y * t.x};
+        }
+    }
+    const double sc = 1.0 / (double)Mc;
+    for (int k = 0; k < Mc; k++) {
+        unsigned rk = 0;
+        for (int bit = 0; bit < logMc; bit++) rk |= (((unsigned)k >> bit) & 1u) << (logMc - 1 - bit);
+        bhat[k] = v2d{b[rk].x * sc, b[rk].y * sc};
+    }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_wind = carve((size_t)N * 8), o_undo = carve((size_t)C * sizeof(BinRow)), o_dom = carve((size_t)K * sizeof(BinRow)), o_tw = carve(tw.size() * 16),
+                 o_ch = carve(chirp.size() * 16), o_bh = carve(bhat.size() * 16);
+    std::vector<char> host(off, 0);
+    memcpy(&host[o_wind], h->window.data(), (size_t)N * 8);
+    memcpy(&host[o_undo], h->undo.data(), (size_t)C * sizeof(BinRow)); memcpy(&host[o_dom], h->dom.data(), (size_t)K * sizeof(BinRow));
+    memcpy(&host[o_tw], tw.data(), tw.size() * 16); memcpy(&host[o_ch], chirp.data(), chirp.size() * 16); memcpy(&host[o_bh], bhat.data(), bhat.size() * 16);
+    if (!h->d_blob) HIPCHK(hipMalloc(&h->d_blob, off));
+    HIPCHK(hipMemcpy(h->d_blob, host.data(), off, hipMemcpyHostToDevice));
+    char* d = (char*)h->d_blob;
+    h->dt = DevTables{};
+    h->dt.windowd = (const double*)(d + o_wind);
+    h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
+    h->dt.any.tw = (const v2d*)(d + o_tw); h->dt.any.M = glbig::kSub; h->dt.any.logM = glbig::kLogSub; h->dt.any.bluestein = 0;
+    h->dt.big.chirp = (const v2d*)(d + o_ch); h->dt.big.bhat = (const v2d*)(d + o_bh); h->dt.big.Mc = Mc; h->dt.big.R = Mc / glbig::kSub;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&glbig::k_big_fft), hipFuncAttributeMaxDynamicSharedMemorySize, glbig::kSub * 16));
+    return GOMEL_OK;
+}
+
+// One forward DFT_N per frame of a chunk, as Bluestein's convolution: A (chirped, zero-padded input) -> A = the convolution C, X[k] = chirp[k] C[k].
+// Uses B as the intermediate.  nf frames, buffers [nf][Mc].
+static void big_convolve(gomel_handle* h, hipStream_t s, v2d* A, v2d* B, int64_t nf) {
+    const glbig::BigTables& bt = h->dt.big;
+    const unsigned blocks = (unsigned)(nf * bt.R);
+    const size_t lds = (size_t)glbig::kSub * 16;
+    hipLaunchKernelGGL(glbig::k_big_fft, dim3(blocks), dim3(glany::kAnyThreads), lds, s, (const v2d*)A, B, bt, h->dt.any, bt.bhat, 0, 1);   // conj(FFT(u) . Bhat / Mc)
+    hipLaunchKernelGGL(glbig::k_big_fft, dim3(blocks), dim3(glany::kAnyThreads), lds, s, (const v2d*)B, A, bt, h->dt.any, (const v2d*)nullptr, 0, 1);   // conj(FFT(conj V)) = the convolution
+}
+// Frames a chunk of the big-length path takes at once: two scratch buffers of [frames][Mc] complex doubles, ~1 GiB each at most
+static int64_t big_chunk_frames(const gomel_handle* h, int64_t total_frames) {
+    const int64_t per = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)h->dt.big.Mc * 16));
+    return std::min<int64_t>(total_frames, per);
+}
+// mode 0: one Griffin-Lim iteration x -> yw (windowed frames, [total_frames][N]); 1: ISTFT's write-back from x -> spec; 2: ToMel's |S[k]| -> smag
+static void big_frames(gomel_handle* h, hipStream_t s, int mode, const double* x, const int64_t* d_frame_xoff, int64_t total_frames, v2d* A, v2d* B,
+                       const double* mag, const double* nyq, const double* mid, double* out) {
+    const int N = h->cfg.resolut;
+    const glbig::BigTables& bt = h->dt.big;
+    const int64_t step = big_chunk_frames(h, total_frames);
+    const unsigned gx = (unsigned)std::min<int64_t>((bt.Mc + 255) / 256, 64);
+    for (int64_t f0 = 0; f0 < total_frames; f0 += step) {
+        const int64_t nf = std::min(step, total_frames - f0);
+        hipLaunchKernelGGL(glbig::k_big_prep, dim3(gx, (unsigned)nf), dim3(256), 0, s, x, d_frame_xoff, f0, h->dt.windowd, A, N, bt);
+        big_convolve(h, s, A, B, nf);
+        if (mode == 2) { hipLaunchKernelGGL(glbig::k_big_absmag, dim3(gx, (unsigned)nf), dim3(256), 0, s, (const v2d*)A, f0, out, N, bt); continue; }
+        if (mode == 1) { hipLaunchKernelGGL(glbig::k_big_clamp<1>, dim3(gx, (unsigned)nf), dim3(256), 0, s, (const v2d*)A, B, f0, mag, nyq, mid, out, N, bt); continue; }
+        hipLaunchKernelGGL(glbig::k_big_clamp<0>, dim3(gx, (unsigned)nf), dim3(256), 0, s, (const v2d*)A, B, f0, mag, nyq, mid, (double*)nullptr, N, bt);
+        big_convolve(h, s, B, A, nf);
+        hipLaunchKernelGGL(glbig::k_big_finish, dim3(gx, (unsigned)nf), dim3(256), 0, s, (const v2d*)B, f0, h->dt.windowd, out, N, bt);
+    }
+}
+
 static int upload_tables_generic(gomel_handle* h) {
+    if (h->big) return upload_tables_big(h);
     const int N = h->cfg.resolut, C = N / 2, K = h->cfg.num_mels;
     const bool pow2 = (N & (N - 1)) == 0;
     int Mc = 1, logMc = 0;                              // the convolution length of Bluestein: >= 2N - 1
@@ -387,6 +468,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     if (!h) return GOMEL_ERR_NO_MEMORY;
     h->cfg = *cfg;
     h->generic = !gomel_supported_n(cfg->resolut);
+    h->big = gomel_big_n(cfg->resolut);
     if (const char* e = getenv("GOMEL_POOL_MB")) h->pool.cap = (size_t)std::max(0L, atol(e)) << 20;
     if (cfg->device >= 0) {
         if (cfg->device >= ndev) { delete h; return GOMEL_ERR_NO_DEVICE; }
@@ -578,6 +660,8 @@ struct gomel_batch {
     double* d_nyqd = nullptr;
     double* d_xd[2] = {nullptr, nullptr};
     double* d_ywd = nullptr;
+    v2d* d_bigA = nullptr;      // frame lengths above 8192: two scratch buffers of [chunk frames][Mc] complex doubles (gl_big.hpp)
+    v2d* d_bigB = nullptr;
     double* d_midd = nullptr;   // exported ISTFT at an odd frame length: |spectrogram[f][N/2]| (bin N/2+1's magnitude sits in d_nyqd)
     int64_t* d_frame_xoff = nullptr;
     UttDesc* d_utts = nullptr;
@@ -612,7 +696,7 @@ static void batch_free(gomel_batch* b) {
     gate_forget(b);
     if (b->gate_ev) hipEventDestroy(b->gate_ev);
     void* ptrs[] = {b->d_spec, b->d_mel, b->d_x0, b->d_out, b->d_mag, b->d_nyq, b->d_x[0], b->d_x[1], b->d_yw, b->d_frame_xoff, b->d_utts,
-                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_midd, b->d_xd[0], b->d_xd[1], b->d_ywd,
+                    b->d_segs, b->d_tail[0], b->d_tail[1], b->d_taild[0], b->d_taild[1], b->d_magd, b->d_nyqd, b->d_midd, b->d_xd[0], b->d_xd[1], b->d_ywd, b->d_bigA, b->d_bigB,
                     b->d_frame_utt, b->d_ctl};
     for (void* p : ptrs) if (p) b->h->pool.release(p);
     persist_release(b);
@@ -1088,7 +1172,9 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             for (int it = 0; it < I64g && !persist; it++) {
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it], s));
                 if (b->fast) { HIPCHK(launch_fused_d(b, curd)); if (tm) HIPCHK(hipEventRecord(b->dom_ev[2 * it + 1], s)); curd ^= 1; continue; }
-                if (h->generic)
+                if (h->big)
+                    big_frames(h, s, 0, b->d_xd[curd], b->d_frame_xoff, b->total_frames, b->d_bigA, b->d_bigB, b->d_magd, b->d_nyqd, b->d_midd, b->d_ywd);
+                else if (h->generic)
                     hipLaunchKernelGGL(glany::k_any_frames<glany::kAnyGl>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
                                        b->d_xd[curd], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_ywd, b->total_frames, N, h->dt.windowd, h->dt.any, b->d_midd);
                 else
@@ -1116,7 +1202,9 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 else hipLaunchKernelGGL(k_finalize<double>, dim3(gf), dim3(256), 0, s, b->d_x[cur], out64, b->total_len);
             } else {
             if (tm) HIPCHK(hipEventRecord(b->ev[2], s));
-            if (b->want_spec && h->generic)   // the literal form's clamp step on x_{I-1}, bins 0 ... N/2 (d_magd holds |spectrogram| as the caller gave it)
+            if (b->want_spec && h->big)
+                big_frames(h, s, 1, b->d_xd[curd ^ 1], b->d_frame_xoff, b->total_frames, b->d_bigA, b->d_bigB, b->d_magd, b->d_nyqd, b->d_midd, b->d_spec);
+            else if (b->want_spec && h->generic)   // the literal form's clamp step on x_{I-1}, bins 0 ... N/2 (d_magd holds |spectrogram| as the caller gave it)
                 hipLaunchKernelGGL(glany::k_any_frames<glany::kAnySpec>, dim3((unsigned)b->total_frames), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, s,
                                    b->d_xd[curd ^ 1], b->d_frame_xoff, b->d_magd, b->d_nyqd, b->d_spec, b->total_frames, N, h->dt.windowd, h->dt.any, b->d_midd);
             else if (b->want_spec)   // d_xd[curd ^ 1] is x_{I-1}: the signal whose phases the last iteration imposed on the spectrogram
@@ -1268,7 +1356,7 @@ const char* gomel_strerror(int s) {
     switch (s) {
         case GOMEL_OK: return "ok";
         case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax)";
-        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut not covered: a power of two up to 8192 or any length up to 4096 (FFT test hooks, fp32 I/O, phase and ISTFT write-back: 256 ... 4096 powers of two; ISTFT: even lengths)";
+        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut not covered: any length from 4 to 65536 is (FFT test hooks, target magnitudes and package phase: 256 ... 4096, powers of two)";
         case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
         case GOMEL_ERR_EMPTY: return "empty input";
         case GOMEL_ERR_TABLE_RANGE: return "mel table indexes outside the band/bin range for this configuration";
@@ -1547,6 +1635,11 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         } else {
             alloc((void**)&b->d_ywd, (size_t)b->total_frames * N * 8 * (b->persist ? 3 : 1));
             alloc((void**)&b->d_frame_xoff, (size_t)b->total_frames * 8);
+            if (h->big) {
+                const size_t sc = (size_t)big_chunk_frames(h, b->total_frames) * (size_t)h->dt.big.Mc * 16;
+                alloc((void**)&b->d_bigA, sc);
+                alloc((void**)&b->d_bigB, sc);
+            }
             if (b->persist) {
                 b->ctl_bytes = 16;
                 alloc((void**)&b->d_ctl, b->ctl_bytes);
@@ -2186,6 +2279,7 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
     DeviceGuard dg(h->device); HIPCHK(dg.err);
     GateOrdinary gate_o; gate_o.enter(h, h->stream);   // synchronous entry point: the gate is left (destructor) after its streams have drained
     double *d_wave = nullptr, *d_smag = nullptr, *d_out = nullptr;
+    v2d *d_bigA = nullptr, *d_bigB = nullptr;   // frame lengths above 8192: the convolution's scratch (gl_big.hpp)
     int64_t* d_fx = nullptr;
     int rc = GOMEL_OK;
     PinnedScope pins;                      // big caller buffers: pinned for the call (pageable copies run at a tenth of the rate)
@@ -2195,6 +2289,10 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
     if (h->pool.alloc((void**)&d_wave, tot_w * 8) != hipSuccess || h->pool.alloc((void**)&d_smag, tot_f * (size_t)(H + 1) * 8) != hipSuccess ||
         h->pool.alloc((void**)&d_out, tot_f * (size_t)K * 16) != hipSuccess || h->pool.alloc((void**)&d_fx, tot_f * 8) != hipSuccess) {
         g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
+    }
+    if (!rc && h->big) {
+        const size_t sc = (size_t)big_chunk_frames(h, (int64_t)tot_f) * (size_t)h->dt.big.Mc * 16;
+        if (h->pool.alloc((void**)&d_bigA, sc) != hipSuccess || h->pool.alloc((void**)&d_bigB, sc) != hipSuccess) { g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP; }
     }
     // Chunks of ~32 MB of samples, pipelined over the handle's three streams as in FromMel's batch call: chunk c+1's waveforms go up
     // while chunk c is transformed and chunk c-1's log-mel comes down (a 256 x 10 s call is H2D-bound: 0.9 GB up, 0.27 GB down,
@@ -2223,13 +2321,16 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
             if (hipMemcpyAsync(d_wave + woff[u], wave[u], n_samples[u] * 8, hipMemcpyDefault, h->up_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
         if (!rc && (hipEventRecord(ev_up[cidx], h->up_stream) != hipSuccess || hipStreamWaitEvent(h->stream, ev_up[cidx], 0) != hipSuccess)) rc = GOMEL_ERR_HIP;
         if (rc) break;
-        if (h->generic)
+        if (h->big)
+            big_frames(h, h->stream, 2, d_wave, d_fx + f0, (int64_t)nf, d_bigA, d_bigB, nullptr, nullptr, nullptr, d_smag + f0 * (size_t)(H + 1));
+        else if (h->generic)
             hipLaunchKernelGGL(glany::k_any_frames<glany::kAnyToMel>, dim3((unsigned)nf), dim3(glany::kAnyThreads), (size_t)h->dt.any.M * 16, h->stream,
                                d_wave, d_fx + f0, (const double*)nullptr, (const double*)nullptr, d_smag + f0 * (size_t)(H + 1), (int64_t)nf, N, h->dt.windowd, h->dt.any);
         else
         GOMEL_DISPATCH_N(N, { constexpr int SPB = 128 / Geo<NN>::T;   /* frame streams per 128-thread block */
                               hipLaunchKernelGGL(k_stft_mag<NN>, dim3((unsigned)((nf + SPB - 1) / SPB)), dim3(128), 0, h->stream, d_wave, d_fx + f0, d_smag + f0 * (size_t)(H + 1), (int64_t)nf, hop, h->dt); });
-        hipLaunchKernelGGL(k_domel_log, dim3((unsigned)nf), dim3(256), (size_t)(H + 1) * 8, h->stream, d_smag + f0 * (size_t)(H + 1), h->dt.dom, d_out + f0 * (size_t)K * 2, K, H);
+        if (h->big) hipLaunchKernelGGL(k_domel_log, dim3((unsigned)nf), dim3(256), 0, h->stream, d_smag + f0 * (size_t)(H + 1), h->dt.dom, d_out + f0 * (size_t)K * 2, K, H, 0);
+        else hipLaunchKernelGGL(k_domel_log, dim3((unsigned)nf), dim3(256), (size_t)(H + 1) * 8, h->stream, d_smag + f0 * (size_t)(H + 1), h->dt.dom, d_out + f0 * (size_t)K * 2, K, H, 1);
         if (hipEventRecord(ev_done[cidx], h->stream) != hipSuccess || hipStreamWaitEvent(h->copy_stream, ev_done[cidx], 0) != hipSuccess) rc = GOMEL_ERR_HIP;
         for (size_t u = u0; u < u1 && !rc; u++)
             if (hipMemcpyAsync(out_pairs[u], d_out + foff[u] * (size_t)K * 2, F[u] * (size_t)K * 16, hipMemcpyDefault, h->copy_stream) != hipSuccess) rc = GOMEL_ERR_HIP;
@@ -2243,6 +2344,8 @@ static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* con
     if (d_smag) h->pool.release(d_smag);
     if (d_out) h->pool.release(d_out);
     if (d_fx) h->pool.release(d_fx);
+    if (d_bigA) h->pool.release(d_bigA);
+    if (d_bigB) h->pool.release(d_bigB);
     if (!rc && n_pairs_out) for (size_t u = 0; u < n_utt; u++) n_pairs_out[u] = F[u] * (size_t)K;
     return rc;
 }

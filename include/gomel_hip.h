@@ -84,9 +84,10 @@ int gomel_default_config(gomel_config* cfg);
 
 /* Replaces stft.New(m.Window, m.Resolut) (mel/mel.go:50,145) and the per-call index math of undomel/domel
  * (mel/impl.go:311-322,348-359): builds Hann, FFT twiddles and the mel<->linear tables once, uploads them.
- * Resolut: 256, 512, 1024, 2048, 4096 run the tuned register FFT cores; every other length from 4 to 8192 (odd lengths
- * included: the reference's fft.FFTReal / fft.IFFT take any length, mel/mel.go:95,116) runs generic fp64 kernels (radix-2 for
- * powers of two, Bluestein otherwise); anything else is GOMEL_ERR_UNSUPPORTED_N. */
+ * Resolut: 256, 512, 1024, 2048, 4096 run the tuned register FFT cores; every other length from 4 to 65536 (odd lengths
+ * included: the reference's fft.FFTReal / fft.IFFT take any length, mel/mel.go:95,116) runs generic fp64 kernels -- up to 8192 with
+ * the frame in LDS (radix-2 for powers of two, Bluestein otherwise), above that Bluestein's convolution through HBM; anything else
+ * is GOMEL_ERR_UNSUPPORTED_N. */
 int gomel_create(const gomel_config* cfg, gomel_handle** out);
 
 /* Same, from a table blob exported by another handle (the multi-GPU path: rank 0 builds, the blob is broadcast

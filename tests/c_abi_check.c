@@ -20,7 +20,7 @@ int main(void) {
     c.resolut = 3000; if (gomel_tables_bytes_for(&c) == 0) return 10;            /* any length up to 4096 */
     c.resolut = 3001; if (gomel_tables_bytes_for(&c) == 0) return 11;            /* odd lengths too */
     c.resolut = 6000; if (gomel_tables_bytes_for(&c) == 0) return 17;            /* ... and up to 8192 (Bluestein in two halves) */
-    c.resolut = 9000; if (gomel_tables_bytes_for(&c) != 0) return 22;            /* above 8192: refused */
+    c.resolut = 70000; if (gomel_tables_bytes_for(&c) != 0) return 22;           /* above 65536: refused */
     c.resolut = 8192; if (gomel_tables_bytes_for(&c) == 0) return 12;
     c.resolut = 4096;
     {

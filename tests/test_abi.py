@@ -122,7 +122,7 @@ def test_no_device_means_error_not_fallback(L):
 def test_config_validation_statuses(L):
     from gomel_amd._lib import GomelConfig
     h = ctypes.c_void_p()
-    for field, val, status in [("resolut", 8193, 2), ("resolut", 9000, 2), ("resolut", 16384, 2), ("resolut", 2, 2), ("num_mels", 0, 1), ("window", 0, 1), ("window", -3, 1),
+    for field, val, status in [("resolut", 65537, 2), ("resolut", 70000, 2), ("resolut", 131072, 2), ("resolut", 2, 2), ("num_mels", 0, 1), ("window", 0, 1), ("window", -3, 1),
                                ("tune_mul", 0.0, 1), ("mel_fmax", 0.0, 1), ("griffin_lim_iterations", -1, 1)]:
         c = GomelConfig()
         L.gomel_default_config(ctypes.byref(c))

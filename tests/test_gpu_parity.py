@@ -143,7 +143,7 @@ def test_error_statuses():
     with pytest.raises(gomel_amd.GomelError) as ei:
         m.FromMel(np.zeros((0, 2)))
     assert ei.value.status == 4
-    for bad in (8193, 9000, 16384):      # above 8192 (everything up to there the generic kernels take)
+    for bad in (65537, 70000, 131072):   # above 65536 (everything up to there the generic kernels take: gl_any.hpp to 8192, gl_big.hpp beyond)
         m.Resolut = bad
         with pytest.raises(gomel_amd.GomelError) as ei:
             m.FromMel(np.zeros((192, 2)))

@@ -472,10 +472,13 @@ def test_concurrent_batch_calls_on_one_handle(oracle):
 # ------------------------------------------------------------------------------------------------ any Resolut (the reference: go-dsp radix-2 / Bluestein)
 @pytest.mark.parametrize("N,hop,K,fmax", [(8192, 2048, 96, 16000.0), (3000, 750, 64, 8000.0), (1000, 250, 40, 8000.0), (8, 3, 2, 8000.0), (64, 20, 8, 8000.0),
                                            (1001, 250, 40, 8000.0), (4095, 1024, 96, 16000.0), (63, 20, 8, 8000.0),
-                                           (6000, 1500, 96, 16000.0), (4097, 1024, 96, 16000.0), (8191, 2000, 96, 16000.0), (5000, 1250, 80, 8000.0)])   # Bluestein in two halves
+                                           (6000, 1500, 96, 16000.0), (4097, 1024, 96, 16000.0), (8191, 2000, 96, 16000.0), (5000, 1250, 80, 8000.0),   # Bluestein in two halves
+                                           (16384, 4096, 128, 16000.0), (10000, 2500, 96, 16000.0), (12001, 3000, 96, 16000.0), (8193, 2048, 96, 16000.0),   # above 8192: gl_big.hpp, through HBM
+                                           (40000, 9000, 160, 20000.0), (65536, 16384, 192, 22000.0)])
 def test_any_frame_length_from_mel_to_mel_istft(oracle, N, hop, K, fmax):
     """The reference takes any frame length (fft.FFTReal / fft.IFFT, mel/mel.go:95,116); outside 256 ... 4096 powers of two the
-    generic kernels (gl_any.hpp: radix-2 in LDS, Bluestein for the rest, fp64) carry FromMel, ToMel and ISTFT."""
+    generic kernels (gl_any.hpp: radix-2 in LDS, Bluestein for the rest, fp64; above 8192 gl_big.hpp: Bluestein through HBM, up to
+    65536) carry FromMel, ToMel and ISTFT."""
     import gomel_amd
     fields = dict(NumMels=K, MelFmax=fmax, Window=hop, Resolut=N)
     cfg = oracle.MelConfig(GriffinLimIterations=3, **fields)

@@ -119,10 +119,11 @@ def test_tables_fuzz_and_refusals(oracle):
 def test_tables_build_argument_checks():
     from gomel_amd import _lib
     L = _lib.lib()
-    cfg = config(Resolut=9000)
+    cfg = config(Resolut=70000)
     assert L.gomel_tables_bytes_for(ctypes.byref(cfg)) == 0
-    assert L.gomel_tables_bytes_for(ctypes.byref(config(Resolut=3000))) > 0       # any length up to 8192 (radix-2 / Bluestein)
+    assert L.gomel_tables_bytes_for(ctypes.byref(config(Resolut=3000))) > 0       # any length up to 65536 (radix-2 / Bluestein, above 8192 through HBM)
     assert L.gomel_tables_bytes_for(ctypes.byref(config(Resolut=6000))) > 0
+    assert L.gomel_tables_bytes_for(ctypes.byref(config(Resolut=9000))) > 0 and L.gomel_tables_bytes_for(ctypes.byref(config(Resolut=65536))) > 0
     buf = ctypes.create_string_buffer(16)
     assert L.gomel_tables_build(ctypes.byref(cfg), buf, 16) == 2
     cfg = config()

@@ -245,3 +245,56 @@ def test_tomel_command_line(oracle, tmp_path, capsys):
     assert tomel.main(["tomel", str(tmp_path / "missing")]) == 1
     assert "Error generating mel spectrogram: wavNotLoaded" in capsys.readouterr().out
     assert towav.main(["towav", wav + ".png"]) == 0 and os.path.exists(wav + ".png.wav")
+
+
+GEOMS = {
+    "T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096),   # cmd/towav/main.go:30-36
+    "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),      # BASELINE config 4
+    "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048),     # NewMel defaults mel/mel.go:30-41
+    "Q": dict(NumMels=64, MelFmax=8000.0, Window=160, Resolut=512),       # 16 kHz speech front end
+    "E": dict(NumMels=40, MelFmax=4000.0, Window=80, Resolut=256),        # 8 kHz telephony
+    "A": dict(NumMels=80, MelFmax=8000.0, Window=300, Resolut=1024),      # a hop off the N/16 grid: the any-hop fused kernels
+    "O": dict(NumMels=80, MelFmax=8000.0, Window=275, Resolut=2048),      # ... an odd one (12.5 ms at 22.05 kHz)
+}
+
+
+@pytest.mark.parametrize("iters", [1, 2, 5, 13, 60])
+@pytest.mark.parametrize("geom,frames", [("T", [4]), ("T", [1]), ("T", [40, 9, 1]), ("S", [70, 3, 8]), ("D", [33, 6]), ("Q", [90, 1, 5]), ("E", [130, 7]), ("A", [60, 33, 47]), ("O", [50, 70])])
+def test_default_mode_on_every_path_and_shape(oracle, geom, frames, iters, monkeypatch):
+    """What a caller gets without a knob, through EVERY kernel path (the library's choice, the generic pair, the fused kernels, the
+    persistent kernel where the geometry admits it), on ragged batches of every geometry incl. hops off the N/16 grid and an odd hop:
+    the oracle within 1e-5 (the schedule's fp32 tail sits at 1e-7; one iteration, or k = I, is fp64 throughout: 1e-10), the persistent
+    kernel the generic pair's bits, explicit x0 and seeded starts, the in-place exp of FromMel."""
+    import gomel_amd
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    if iters == 60 and sum(frames) > 60:
+        iters = 24                                                     # keep the oracle side to seconds
+    fields = dict(GEOMS[geom], GriffinLimIterations=iters)
+    cfg = oracle.MelConfig(**fields)
+    K = fields["NumMels"]
+    mels = [oracle.random_logmel(f, K, seed=300 + 7 * i + f) for i, f in enumerate(frames)]
+    x0s = [oracle.x0_splitmix(11 + i, oracle.out_len(cfg, len(mm))) if i % 2 == 0 else None for i, mm in enumerate(mels)]
+    seeds = [900 + i for i in range(len(frames))]
+    wants = [oracle.from_mel(cfg, mm.copy(), x0 if x0 is not None else oracle.x0_splitmix(sd, oracle.out_len(cfg, len(mm)))) for mm, x0, sd in zip(mels, x0s, seeds)]
+    m = mel_obj(fields)
+    eng = m.engine()
+    k = eng.fp64_iterations()
+    tol = 1e-10 if k >= iters else 1e-5
+    outs = {}
+    for path in (0, 1, 2, 3):
+        try:
+            eng.set_path(path)
+            outs[path] = eng.from_mel_batch(mels, x0s, seeds)
+        except gomel_amd.GomelError as ex:
+            assert ex.status == 1 and path in (2, 3), (path, ex)      # a path this geometry / batch does not admit: bad configuration, nothing else
+            continue
+        for o, w in zip(outs[path], wants):
+            assert o.shape == w.shape and np.all(np.isfinite(o))
+            assert rms(o - w) < tol * max(1.0, rms(w)), (path, rms(o - w), k, iters)
+    assert 0 in outs and 1 in outs
+    if 3 in outs:
+        assert all(np.array_equal(a, b) for a, b in zip(outs[3], outs[1]))
+    eng.set_path(0)
+    one = mels[0].copy()
+    got = m.FromMel(one, x0=x0s[0])                                    # the single-call entry point, side effect included (mel/mel.go:143)
+    assert rms(got - wants[0]) < tol * max(1.0, rms(wants[0])) and np.allclose(one, np.exp(mels[0]), rtol=1e-15)

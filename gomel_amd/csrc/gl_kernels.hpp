@@ -88,10 +88,13 @@ template <class InT> GL_DEV double apply_row_ch1(const BinRow r, const InT* __re
 
 // InT: element type of the log-mel pairs as the caller handed them over (double: the Go API's [][2]float64; float: the fp32
 // host-I/O entry points).  The arithmetic is fp64 either way.
+// mag32 / nyq32 (nullable; precision schedules): the same rows once more, rounded to float -- the fp32 kernels' magnitudes leave in the
+// same pass that makes the fp64 kernels' (what a separate narrowing pass would give, bit for bit, without re-reading 16 KB per frame).
 template <int N, class MagT, class InT>
 __global__ __launch_bounds__(256) void k_mel_to_mag(const InT* __restrict__ mel, const BinRow* __restrict__ undo,
                                                     MagT* __restrict__ mag, MagT* __restrict__ nyq, int K, int64_t n_frames,
-                                                    double tune_add, double tune_mul, double inv_n, int FPB) {
+                                                    double tune_add, double tune_mul, double inv_n, int FPB, float* __restrict__ mag32 = nullptr,
+                                                    float* __restrict__ nyq32 = nullptr) {
     constexpr int H = N / 2, PER = H < 256 ? 1 : H / 256;   // N 256: half the block's lanes idle in the bin loops
     extern __shared__ double e_sh[];                       // [FPB][K] exp(channel 0), then the staged row [H] of MagT
     MagT* row = reinterpret_cast<MagT*>(e_sh + FPB * K);
@@ -124,19 +127,25 @@ __global__ __launch_bounds__(256) void k_mel_to_mag(const InT* __restrict__ mel,
                 double v1 = apply_row_ch1(r[j], m0 + (int64_t)ff * K * 2) - tune_add;
                 if (!unit_mul) v1 /= tune_mul;
                 nyq[f] = (MagT)(fabs(v1) * inv_n);
+                if (nyq32) nyq32[f] = (float)(MagT)(fabs(v1) * inv_n);
             }
         }
         __syncthreads();
         MagT* o = mag + f * H;
 #pragma unroll
         for (int j = 0; j < PER; j++) if (has_bin) o[threadIdx.x + 256 * j] = row[threadIdx.x + 256 * j];
+        if (mag32) {
+            float* o32 = mag32 + f * H;
+#pragma unroll
+            for (int j = 0; j < PER; j++) if (has_bin) o32[threadIdx.x + 256 * j] = (float)row[threadIdx.x + 256 * j];
+        }
         __syncthreads();                                   // the next frame overwrites the staged row
     }
 }
 
 template <class MagT, class InT>
 static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const InT* mel, const BinRow* undo, MagT* mag, MagT* nyq,
-                                    int K, double tune_add, double tune_mul) {
+                                    int K, double tune_add, double tune_mul, float* mag32 = nullptr, float* nyq32 = nullptr) {
     const double inv_n = 1.0 / (double)N;
     // frames per block: as many exp() rows as fit the default 64 KiB of dynamic LDS next to the staged output row, at most
     // kMagFramesPerBlock; a single row that does not fit (NumMels > ~7 k) raises the kernel's limit towards the 160 KiB of the CU.
@@ -149,7 +158,7 @@ static hipError_t launch_mel_to_mag(int N, int64_t frames, hipStream_t s, const 
     hipError_t e = hipSuccess;
     GOMEL_DISPATCH_N(N, {
         if (shmem > budget) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mel_to_mag<NN, MagT, InT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e == hipSuccess) hipLaunchKernelGGL((k_mel_to_mag<NN, MagT, InT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n, fpb);
+        if (e == hipSuccess) hipLaunchKernelGGL((k_mel_to_mag<NN, MagT, InT>), dim3(blocks), dim3(256), shmem, s, mel, undo, mag, nyq, K, frames, tune_add, tune_mul, inv_n, fpb, mag32, nyq32);
     });
     return e;
 }

@@ -1083,14 +1083,18 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 else if (b->io32) hipLaunchKernelGGL(k_mel_to_mag_nat<float>, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel32, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
                 else hipLaunchKernelGGL(k_mel_to_mag_nat<double>, dim3((unsigned)b->total_frames), dim3(256), 0, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, N / 2, c.tune_add, c.tune_mul);
             }
+            // (a precision schedule's fp32 magnitudes -- the fp64 rows rounded once -- leave in the same pass; from linear magnitudes they are narrowed below)
+            const bool want32 = !h->generic && (b->mixed_k > 0 || b->pmix_k > 0);
+            float* m32 = want32 && !b->direct ? b->d_mag : nullptr;
+            float* n32 = want32 && !b->direct ? b->d_nyq : nullptr;
+            if (h->generic) {}
             else if (b->direct) launch_mag_direct<double>(N, b->total_frames, s, mel64, b->d_magd, b->d_nyqd);
-            else if (b->io32) HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel32, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
-            else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul));
+            else if (b->io32) HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel32, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul, m32, n32));
+            else HIPCHK(launch_mel_to_mag<double>(N, b->total_frames, s, mel64, h->dt.undo, b->d_magd, b->d_nyqd, K, c.tune_add, c.tune_mul, m32, n32));
             if (b->io32) hipLaunchKernelGGL((k_init_x<double, float>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x032, b->d_xd[0]);   // float host buffers
             else hipLaunchKernelGGL((k_init_x<double, double>), dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, x064, b->d_xd[0]);
-            if (b->mixed_k) {
-                // the fp32 kernel's magnitudes: the same fp64 values rounded once -- k_mel_to_mag<float> computes in fp64 and rounds on
-                // the store, in the same lane-slot order, so narrowing the fp64 rows gives its very bits at a third of its time
+            if (b->mixed_k && b->direct) {
+                // (from linear magnitudes, gomel_istft:) the fp32 kernel's magnitudes are the fp64 rows rounded once, in the same lane-slot order
                 const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
                 hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
                 hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
@@ -1136,10 +1140,12 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 const int I64 = b->pmix_k ? b->pmix_k : I;          // precision schedule: the fp64 launch covers the first pmix_k iterations only
                 HIPCHK(hipMemsetAsync(b->d_ctl, 0, b->ctl_bytes, s));
                 HIPCHK(hipMemsetAsync(b->d_ywd, 0xff, buf_doubles * 8, s));
-                if (b->pmix_k) {   // the fp32 launch's magnitudes: the fp64 rows rounded once (as on the fused path); its exchange buffer starts as "not stored yet"
-                    const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
-                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
-                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
+                if (b->pmix_k) {   // the fp32 launch: its magnitudes left k_mel_to_mag beside the fp64 rows (linear magnitudes: narrowed here); its exchange buffer starts as "not stored yet"
+                    if (b->direct) {
+                        const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
+                        hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
+                        hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
+                    }
                     HIPCHK(hipMemsetAsync(b->d_yw, 0xff, buf_doubles * 4, s));
                 }
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
@@ -1183,10 +1189,12 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 hipLaunchKernelGGL(k_ola<double>, dim3(gx, gy), dim3(256), 0, s, b->d_utts, (int)b->n_utt, b->d_ywd, b->d_xd[curd ^ 1], N, c.window);
                 curd ^= 1;
             }
-            if (gmix) {   // hand-over: the fp32 magnitudes are the fp64 rows rounded once, the signal likewise; then the fp32 generic pair
-                const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
-                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
-                hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
+            if (gmix) {   // hand-over: the signal rounded to fp32 once (the fp32 magnitudes left k_mel_to_mag beside the fp64 rows; linear magnitudes: narrowed here); then the fp32 generic pair
+                if (b->direct) {
+                    const int64_t nm = b->total_frames * (int64_t)(N / 2), nn = (b->total_frames + 3) & ~(int64_t)3;
+                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nm / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_magd, b->d_mag, nm);
+                    hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((nn / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_nyqd, b->d_nyq, nn);
+                }
                 hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[curd], b->d_x[0], b->total_len);
                 int cur = 0;
                 for (int it = I64g; it < I; it++) {

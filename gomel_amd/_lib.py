@@ -61,6 +61,7 @@ SYMBOLS = {
     "gomel_set_call_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_job_poll": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     "gomel_plan_chunks": (ctypes.c_int, [_cfg_p, ctypes.c_size_t, c_size_p, c_size_p, ctypes.c_size_t, c_size_p]),
+    "gomel_plan_chunks_mode": (ctypes.c_int, [_cfg_p, ctypes.c_int32, ctypes.c_size_t, c_size_p, c_size_p, ctypes.c_size_t, c_size_p]),
     "gomel_host_alloc": (_vp, [ctypes.c_size_t]),
     "gomel_host_free": (ctypes.c_int, [_vp]),
     "gomel_host_register": (ctypes.c_int, [_vp, ctypes.c_size_t]),

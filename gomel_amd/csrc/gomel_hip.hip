@@ -1798,7 +1798,10 @@ int gomel_batch_destroy(gomel_batch* b) {
 
 // How a host-to-host call is cut into chunks: bounds[0] = 0 < bounds[1] < ... < bounds[n_chunks] = n_utt (utterance indices).  Host
 // logic only (exported as gomel_plan_chunks, tested without a GPU).  Lengths must already be validated (multiples of NumMels, > 0).
-static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, const size_t* n_pairs) {
+// `heavy`: the call runs fp64 iterations (precision schedule / 64-bit mode) -- its kernels take 1.75-2.4x as long per frame while its copies
+// stay the same, so chunks twice the size still hide them and pay half the chunk-sized launches: 75.8 ms against 79.0 per 256 x 400-frame
+// call in the default mode (scripts/chunk_sweep_default.py, profiles/r04/chunk_sweep_default.txt).
+static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, const size_t* n_pairs, bool heavy) {
     const int K = cfg.num_mels;
     int64_t total_frames = 0;
     for (size_t u = 0; u < n_utt; u++) total_frames += (int64_t)(n_pairs[u] / (size_t)K);
@@ -1808,7 +1811,7 @@ static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, co
     // Resolut 4096 (half a round of the chip, 85 us per launch) and ~32k below (shorter frames: the same launch time; at the TTS
     // geometry three full chunks' worth, 13.5 ms, against 16.1 for eight equal chunks).  More, smaller chunks pay launch overhead and
     // per-segment prologues; fewer expose more of the first upload and the last download.
-    const int64_t kMinChunkFrames = cfg.resolut >= 4096 ? 12288 : 32768;
+    const int64_t kMinChunkFrames = (cfg.resolut >= 4096 ? 12288 : 32768) * (heavy ? 2 : 1);
     const int m_full = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
     int n_chunks = total_frames < kMinChunkFrames ? 1 : m_full + 1;
     std::vector<double> shares;   // relative chunk sizes
@@ -1887,7 +1890,9 @@ static int from_mel_batch_chunked(gomel_handle* h, size_t n_utt, const void* con
         if (out_cap && out_cap[u] < L) return GOMEL_ERR_BUFFER_TOO_SMALL;
         total_frames += (int64_t)(n_pairs[u] / (size_t)K);
     }
-    std::vector<size_t> bounds = plan_chunks(h->cfg, n_utt, n_pairs);
+    bool heavy;
+    { std::lock_guard<std::mutex> lk(h->mu); heavy = resolve_fp64_iterations(h, h->cfg.griffin_lim_iterations) > 0; }
+    std::vector<size_t> bounds = plan_chunks(h->cfg, n_utt, n_pairs, heavy);
     int n_chunks = (int)bounds.size() - 1;
     struct ChunkList {
         std::vector<gomel_batch*> v;
@@ -2573,7 +2578,7 @@ int gomel_debug_stamps(unsigned long long* out21, int clear) {
 #endif
 
 // ---- host memory helpers: pinned buffers a bulk caller reuses across calls (no per-call hipHostRegister)
-int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks) {
+int gomel_plan_chunks_mode(const gomel_config* cfg, int32_t fp64_iterations, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks) {
     if (!cfg || !n_pairs || !bounds || !n_chunks) return GOMEL_ERR_NULL;
     if (n_utt == 0) return GOMEL_ERR_EMPTY;
     if (cfg->num_mels <= 0 || cfg->window <= 0 || cfg->resolut < 4) return GOMEL_ERR_BAD_CONFIG;
@@ -2582,12 +2587,16 @@ int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pai
         if (n_pairs[u] % (size_t)cfg->num_mels) return GOMEL_ERR_BAD_LENGTH;
     }
     GOMEL_TRY
-    const std::vector<size_t> b = plan_chunks(*cfg, n_utt, n_pairs);
+    if (fp64_iterations == GOMEL_SCHEDULE_AUTO) fp64_iterations = gomel_auto_fp64_iterations(cfg, cfg->griffin_lim_iterations);
+    const std::vector<size_t> b = plan_chunks(*cfg, n_utt, n_pairs, fp64_iterations != 0 || !gomel_supported_n(cfg->resolut));
     if (b.size() > cap) return GOMEL_ERR_BUFFER_TOO_SMALL;
     for (size_t i = 0; i < b.size(); i++) bounds[i] = b[i];
     *n_chunks = b.size() - 1;
     return GOMEL_OK;
     GOMEL_CATCH
+}
+int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks) {
+    return gomel_plan_chunks_mode(cfg, GOMEL_SCHEDULE_AUTO, n_utt, n_pairs, bounds, cap, n_chunks);
 }
 
 void* gomel_host_alloc(size_t bytes) {

@@ -106,14 +106,16 @@ class Engine:
         check(_lib.lib().gomel_get_precision(self._h, int(iterations), ctypes.byref(k)), "gomel_get_precision")
         return k.value
 
-    def plan_chunks(self, n_pairs):
-        """gomel_plan_chunks: how a gomel_from_mel_batch call over utterances of these lengths is cut -- the utterance indices
-        [0, b1, ..., n] at which its chunks begin and end (host logic, no device work)."""
+    def plan_chunks(self, n_pairs, fp64_iterations=None):
+        """gomel_plan_chunks_mode: how a gomel_from_mel_batch call over utterances of these lengths is cut -- the utterance indices
+        [0, b1, ..., n] at which its chunks begin and end (host logic, no device work) -- for a call with that many fp64 iterations
+        (None: what this engine's current precision mode gives; 0: the fp32 fast mode)."""
         n = len(n_pairs)
         np_ = (ctypes.c_size_t * max(n, 1))(*[int(v) for v in n_pairs])
         bounds = (ctypes.c_size_t * (n + 2))()
         nch = ctypes.c_size_t(0)
-        check(_lib.lib().gomel_plan_chunks(ctypes.byref(self.cfg), n, np_, bounds, n + 2, ctypes.byref(nch)), "gomel_plan_chunks")
+        k = self.fp64_iterations() if fp64_iterations is None else int(fp64_iterations)
+        check(_lib.lib().gomel_plan_chunks_mode(ctypes.byref(self.cfg), k, n, np_, bounds, n + 2, ctypes.byref(nch)), "gomel_plan_chunks_mode")
         return [int(bounds[i]) for i in range(nch.value + 1)]
 
     def device_name(self):

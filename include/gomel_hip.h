@@ -190,9 +190,12 @@ int gomel_host_unregister(void* p);
 /* How gomel_from_mel_batch / _f32 will cut a call with these utterance lengths into the chunks it pipelines (upload c+1 | compute
  * c | download c-1): writes *n_chunks + 1 utterance indices 0 = bounds[0] < ... < bounds[*n_chunks] = n_utt.  Host logic only (no
  * device needed); bounds needs room for at most 66 entries (cap = its capacity).  The plan: half-size first and last chunks, full
- * chunks of ~12k frames at Resolut 4096 / ~32k below, boundaries moved by up to two utterances to where a chunk fills the fused
- * kernel's rounds; GOMEL_CHUNKS / GOMEL_CHUNK_SHARES override it. */
+ * chunks of ~12k frames at Resolut 4096 / ~32k below -- twice that for calls that run fp64 iterations (their kernels take longer per
+ * frame, so larger chunks still hide the copies) --, boundaries moved by up to two utterances to where a chunk fills the fused
+ * kernel's rounds; GOMEL_CHUNKS / GOMEL_CHUNK_SHARES override it.  gomel_plan_chunks: a handle in its default (automatic) precision
+ * mode; gomel_plan_chunks_mode: a call with that many fp64 iterations (0 = the fp32 fast mode, GOMEL_SCHEDULE_AUTO = the default). */
 int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks);
+int gomel_plan_chunks_mode(const gomel_config* cfg, int32_t fp64_iterations, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks);
 
 /* The same work split so that inputs can be resident in HBM before the clock starts (bench / pipelines):
  * create (plan + allocate) -> upload (H2D of log-mel and x0) -> run (all device work, asynchronous on the

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 
-def plan(L, fields, frames):
+def plan(L, fields, frames, fp64_iterations=0):
+    """fp64_iterations = 0: the plan of the fp32 fast mode (what rounds 2-3 tuned); None: gomel_plan_chunks, i.e. the default precision mode"""
     from gomel_amd._lib import GomelConfig
     c = GomelConfig()
     L.gomel_default_config(ctypes.byref(c))
@@ -16,7 +17,10 @@ def plan(L, fields, frames):
     npairs = (ctypes.c_size_t * n)(*[f * c.num_mels for f in frames])
     bounds = (ctypes.c_size_t * 66)()
     nch = ctypes.c_size_t(0)
-    rc = L.gomel_plan_chunks(ctypes.byref(c), n, npairs, bounds, 66, ctypes.byref(nch))
+    if fp64_iterations is None:
+        rc = L.gomel_plan_chunks(ctypes.byref(c), n, npairs, bounds, 66, ctypes.byref(nch))
+    else:
+        rc = L.gomel_plan_chunks_mode(ctypes.byref(c), fp64_iterations, n, npairs, bounds, 66, ctypes.byref(nch))
     return rc, [bounds[i] for i in range(nch.value + 1)]
 
 
@@ -85,3 +89,22 @@ def test_overrides_and_errors(L, monkeypatch):
     npairs = (ctypes.c_size_t * 64)(*([192 * 400] * 64))
     c.num_mels, c.window, c.resolut = 192, 1280, 4096
     assert L.gomel_plan_chunks(ctypes.byref(c), 64, npairs, bounds, 2, ctypes.byref(nch)) == 6        # bounds too small
+
+
+def test_calls_with_fp64_iterations_take_chunks_twice_the_size(L, monkeypatch):
+    """The default precision mode (and any schedule / 64-bit mode) runs fp64 launches that take 1.75-2.4x as long per frame: chunks of
+    ~24k frames still hide the copies and halve the number of chunk-sized launches (75.8 ms against 79.0 per config-3 call)."""
+    from gomel_amd._lib import SCHEDULE_AUTO
+    monkeypatch.delenv("GOMEL_CHUNKS", raising=False)
+    monkeypatch.delenv("GOMEL_CHUNK_SHARES", raising=False)
+    t60 = dict(T, griffin_lim_iterations=60)
+    rc, fast = plan(L, t60, [400] * 256, 0)
+    rc2, dflt = plan(L, t60, [400] * 256, None)
+    rc3, auto = plan(L, t60, [400] * 256, SCHEDULE_AUTO)
+    rc4, full = plan(L, t60, [400] * 256, -1)
+    assert rc == rc2 == rc3 == rc4 == 0 and dflt == auto == full
+    assert len(fast) - 1 == 9 and len(dflt) - 1 == 5                 # half + 7 + half against half + 3 + half
+    sizes = np.diff(dflt)
+    assert sizes[0] < 0.7 * np.median(sizes) and sizes[-1] < 0.7 * np.median(sizes) and dflt[-1] == 256
+    assert plan(L, t60, [400] * 32, None) == (0, [0, 32])            # below one (doubled) full chunk: no pipelining
+    assert L.gomel_plan_chunks_mode(None, 0, 1, None, None, 0, None) == 7

@@ -298,3 +298,22 @@ def test_default_mode_on_every_path_and_shape(oracle, geom, frames, iters, monke
     one = mels[0].copy()
     got = m.FromMel(one, x0=x0s[0])                                    # the single-call entry point, side effect included (mel/mel.go:143)
     assert rms(got - wants[0]) < tol * max(1.0, rms(wants[0])) and np.allclose(one, np.exp(mels[0]), rtol=1e-15)
+
+
+def test_big_frame_lengths_in_chunks_of_frames(oracle):
+    """gl_big.hpp keeps its two scratch buffers at <= 1 GiB: a batch of more frames than fit goes through in chunks of frames (2048 at
+    Resolut 9000, whose convolution has 32768 points).  2100 frames in two utterances, one iteration, against the oracle; ToMel of a
+    signal that long likewise."""
+    fields = dict(NumMels=64, MelFmax=16000.0, Window=9000, Resolut=9000, GriffinLimIterations=1)
+    cfg = oracle.MelConfig(**fields)
+    m = mel_obj(fields)
+    mels = [oracle.random_logmel(f, 64, seed=f) for f in (2070, 30)]
+    x0s = [oracle.x0_splitmix(5 + i, oracle.out_len(cfg, len(mm))) for i, mm in enumerate(mels)]
+    got = m.engine().from_mel_batch(mels, x0s, None)
+    for g, mm, x0 in zip(got, mels, x0s):
+        want = oracle.from_mel(cfg, mm.copy(), x0)
+        assert g.shape == want.shape and rms(g - want) < 1e-9 * max(1.0, rms(want))
+    sig = np.random.default_rng(3).standard_normal(9000 * 2100) * 0.1
+    gotm = m.ToMel(sig)
+    wantm = oracle.to_mel(cfg, sig)
+    assert gotm.shape == wantm.shape and np.max(np.abs(gotm - wantm)) < 1e-8

@@ -380,7 +380,7 @@ def main():
     ap.add_argument("--depth", type=int, default=DEPTH, help="calls in flight in the timed region (0 or 1: one synchronous call after the other)")
     ap.add_argument("--parity", default=None, choices=["all", "sample", "none"], help="oracle check of the timed batch: a ~25 s sample of its utterances (default), all of them, or none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (baseline + parity)")
-    ap.add_argument("--no-single", action="store_true", help="skip the side measurements (configs[1], configs[0], pageable buffers)")
+    ap.add_argument("--no-single", action="store_true", help="skip the side measurements (the lone synchronous caller, configs[1], configs[0], pageable buffers)")
     ap.add_argument("--no-modes", "--no-precise", dest="no_modes", action="store_true", help="skip the other precision modes' legs")
     args = ap.parse_args()
 
@@ -483,7 +483,7 @@ def main():
     solo = rank == 0 and world == 1
     outs_by_mode = {args.mode: outs_last}
     single_caller = None
-    if solo:
+    if solo and not args.no_single:
         def single_caller_leg():
             el, _, _, _ = host_to_host(engine, fields, n_utt, frames, first, max(3, args.steps // 3), 1, lambda: None, depth=0)
             return n_utt * frames * max(3, args.steps // 3) / el

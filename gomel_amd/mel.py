@@ -273,6 +273,35 @@ class Engine:
                                                      bound.caps.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), ctypes.byref(job)), "gomel_from_mel_batch_submit")
         return Job(job, bound)
 
+    def submit_f32(self, mels, x0s=None, seeds=None, outs=None):
+        """gomel_from_mel_batch_submit_f32: the float32 host-I/O call as a job (see submit_bound).  The arrays are kept alive by the
+        returned Job; Job.wait() returns the float32 waveforms."""
+        ms = [np.ascontiguousarray(m, dtype=np.float32) for m in mels]
+        n = len(ms)
+        if n == 0 or any(m.ndim != 2 or m.shape[1] != 2 for m in ms):
+            raise ValueError("expected a non-empty list of [n, 2] arrays")
+        lens = [self.out_len(len(m)) for m in ms]
+        if outs is None:
+            outs = [np.empty(max(L, 1), dtype=np.float32) for L in lens]
+        elif len(outs) != n or any(o.dtype != np.float32 or o.ndim != 1 or len(o) < L or not o.flags.c_contiguous for o, L in zip(outs, lens)):
+            raise ValueError("outs must be C-contiguous float32 arrays of at least the output lengths")
+        xs = None if x0s is None else [None if x is None else np.ascontiguousarray(x, dtype=np.float32) for x in x0s]
+        fpp = ctypes.POINTER(_lib.c_float_p)
+        mp = (_lib.c_float_p * n)(*[m.ctypes.data_as(_lib.c_float_p) for m in ms])
+        op = (_lib.c_float_p * n)(*[o.ctypes.data_as(_lib.c_float_p) for o in outs])
+        xp = None if xs is None else (_lib.c_float_p * n)(*[None if x is None else x.ctypes.data_as(_lib.c_float_p) for x in xs])
+        sp = None if seeds is None else (ctypes.c_uint64 * n)(*[int(s_) & (2 ** 64 - 1) for s_ in seeds])
+        npairs = (ctypes.c_size_t * n)(*[len(m) for m in ms])
+        caps = (ctypes.c_size_t * n)(*[len(o) for o in outs])
+        job = ctypes.c_void_p()
+        check(_lib.lib().gomel_from_mel_batch_submit_f32(self._h, n, ctypes.cast(mp, fpp), npairs, None if xp is None else ctypes.cast(xp, fpp), sp,
+                                                         ctypes.cast(op, fpp), caps, ctypes.byref(job)), "gomel_from_mel_batch_submit_f32")
+
+        class _Views:
+            views = [o[:L] for o, L in zip(outs, lens)]
+            keep = (ms, xs, outs)
+        return Job(job, _Views)
+
     def target_magnitudes(self, mel_pairs):
         m = _as_pairs(mel_pairs)
         H = self.cfg.resolut // 2

@@ -317,3 +317,20 @@ def test_big_frame_lengths_in_chunks_of_frames(oracle):
     gotm = m.ToMel(sig)
     wantm = oracle.to_mel(cfg, sig)
     assert gotm.shape == wantm.shape and np.max(np.abs(gotm - wantm)) < 1e-8
+
+
+def test_float_host_buffers_as_jobs(oracle, monkeypatch):
+    """gomel_from_mel_batch_submit_f32: two float32 calls in flight equal the synchronous float32 call in whole-batch call mode, bit for bit."""
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    fields = dict(S, GriffinLimIterations=9)
+    K, U, F = 80, 48, 200
+    eng = mel_obj(fields).engine()
+    sets = [[a.astype(np.float32) for a in inputs(U, F, K, first=50 * i)[0]] for i in range(2)]
+    seeds = [list(range(10 * i, 10 * i + U)) for i in range(2)]
+    jobs = [eng.submit_f32(sets[i], None, seeds[i]) for i in range(2)]
+    got = [[np.array(v) for v in j.wait()] for j in jobs]
+    eng.set_call_mode(1)
+    for i in range(2):
+        want = eng.from_mel_batch_f32(sets[i], None, seeds[i])
+        assert all(g.dtype == np.float32 and np.array_equal(g, w) for g, w in zip(got[i], want))
+    eng.close()

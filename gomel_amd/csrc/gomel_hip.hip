@@ -113,6 +113,7 @@ struct gomel_handle {
     hipStream_t copy_stream = nullptr;  // D2H of finished chunks, overlapped with the next chunk's compute
     hipStream_t up_stream = nullptr;    // H2D of the next chunk, overlapped with this chunk's compute
     std::mutex mu;
+    std::atomic<int> jobs_outstanding{0};  // submitted jobs not yet waited for: gomel_destroy refuses while there are any
     std::atomic<int> call_mode{0};         // gomel_set_call_mode: 0 = a synchronous batch call is chunked, 1 = it is one whole batch (submit + wait)
     int path_mode = 0;
     // Arithmetic of the Griffin-Lim iterations (gomel_set_precision / gomel_set_precision_schedule): kPrecAuto (default) = the
@@ -1493,6 +1494,7 @@ int gomel_get_precision(const gomel_handle* h, int32_t iterations, int32_t* fp64
 
 int gomel_destroy(gomel_handle* h) {
     if (!h) return GOMEL_OK;
+    if (h->jobs_outstanding.load() != 0) return GOMEL_ERR_NULL;   // call out of order: a submitted job has not been waited for (its buffers live in this handle)
     {
     DeviceGuard dg(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
@@ -2016,6 +2018,7 @@ struct gomel_job {
 static void job_drop(gomel_job* j) {  // caller has made sure nothing of the job is still in flight
     if (j->b) { std::lock_guard<std::mutex> lk(j->h->mu); batch_free(j->b); j->b = nullptr; }
     for (hipEvent_t e : {j->up, j->done, j->down}) if (e) hipEventDestroy(e);
+    j->h->jobs_outstanding--;
     delete j;                         // releases the pins (no stream is drained: the caller has done what was needed)
 }
 
@@ -2042,6 +2045,7 @@ static int submit_guarded(gomel_handle* h, size_t n_utt, const void* const* mel,
     gomel_job* j = new (std::nothrow) gomel_job();
     if (!j) return GOMEL_ERR_NO_MEMORY;
     j->h = h;
+    h->jobs_outstanding++;
     if (!whole_batch_pays(h, n_utt, n_pairs)) {   // small: run it now, hand back a finished job
         j->status = from_mel_batch_chunked(h, n_utt, mel, n_pairs, x0, seeds, out, out_cap, io32);
         j->completed = true;

@@ -105,7 +105,8 @@ int gomel_tables_build(const gomel_config* cfg, void* blob, size_t cap);
 int gomel_set_window(gomel_handle* h, const double* window, size_t n);
 int gomel_get_window(const gomel_handle* h, double* window, size_t cap);
 
-/* Destroy every gomel_batch created from the handle first. */
+/* Destroy every gomel_batch created from the handle first, and wait for every submitted job: with jobs outstanding the call is
+ * refused (GOMEL_ERR_NULL, "call out of order") and the handle stays valid. */
 int gomel_destroy(gomel_handle* h);
 
 /* len(reconstructedSignal), mel/mel.go:80.  0 on bad arguments. */

@@ -178,6 +178,10 @@ def test_submitted_jobs_equal_the_whole_batch_bit_for_bit(oracle, mode, monkeypa
     assert js.done()
     want = eng.from_mel_batch(small_m, None, small_s)
     assert all(np.array_equal(a, b) for a, b in zip(js.wait(), want))
+    # a handle with a job outstanding refuses to be destroyed (status 7, "call out of order") and stays usable
+    jd = eng.submit_bound(bound[0], sets[0][1])
+    assert gomel_amd._lib.lib().gomel_destroy(eng._h) == 7
+    assert all(np.array_equal(a, b) for a, b in zip(jd.wait(), refs[0]))
     # errors surface at submit, nothing is left in flight
     with pytest.raises(gomel_amd.GomelError):
         eng.submit_bound(eng.bind_buffers([np.zeros((191, 2))], [np.zeros(8192)]), [0])

@@ -64,13 +64,17 @@ def main():
     m0 = gomel_amd.NewMel()
     for k_, v in fields.items():
         setattr(m0, k_, v)
-    for blk in range(blocks):
-        first = blk * U
+    SEED0 = int(os.environ.get("CAL_SEED0", "0"))     # a held-out set: other seeds than the calibration's 0 ... 4095
+
+    def make_block(blk):
+        first = SEED0 + blk * U
         if cls == "random":
-            mels.append([np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)])
-        else:
-            x = signals(first, N + (F - 1) * hop, sr, dev).cpu().numpy()
-            mels.append(m0.engine().to_mel_batch([x[u] for u in range(U)]))
+            return [np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
+        x = signals(first, N + (F - 1) * hop, sr, dev).cpu().numpy()
+        return m0.engine().to_mel_batch([x[u] for u in range(U)])
+    stream = len(grid) == 1                             # one iteration count: blocks are made as they are used (any number of them)
+    for blk in range(1 if stream else blocks):
+        mels.append(make_block(blk))
     frames = len(mels[0][0]) // K
     L = N + (frames - 1) * hop
     print("# %s %s: %d blocks x %d utterances x %d frames, inputs ready after %.0f s" % (geom, cls, blocks, U, frames, time.time() - t0), flush=True)
@@ -85,12 +89,15 @@ def main():
         errs = {k: [] for k in grid[I]}
         rms = []
         for blk in range(blocks):
-            seeds = [1000 + blk * U + u for u in range(U)]
+            seeds = [1000 + SEED0 + blk * U + u for u in range(U)]
+            if stream and blk:
+                mels[0] = make_block(blk)
+            cur = mels[0] if stream else mels[blk]
 
             def run(s, dst):
                 e.set_precision_schedule(s)
                 b = gomel_amd.Batch(e, [frames * K] * U)
-                b.upload(mels[blk], None, seeds)
+                b.upload(cur, None, seeds)
                 b.run()
                 b.download([dst[u] for u in range(U)])
                 b.close()

@@ -338,3 +338,28 @@ def test_float_host_buffers_as_jobs(oracle, monkeypatch):
         want = eng.from_mel_batch_f32(sets[i], None, seeds[i])
         assert all(g.dtype == np.float32 and np.array_equal(g, w) for g, w in zip(got[i], want))
     eng.close()
+
+
+@pytest.mark.parametrize("N,hop,F,I", [(1024, 256, 9, 3), (4096, 1280, 40, 6), (2048, 300, 25, 4)])
+def test_exported_istft_in_the_default_mode(oracle, N, hop, F, I, monkeypatch):
+    """ISTFT(s, spectrogram, numIterations) (mel/mel.go:76-139) on a handle nobody touched: from a list (no write-back: the default
+    schedule on whatever path the batch takes) and from a complex128 array (the write-back runs fp64 throughout), both against the
+    oracle, the latter with the spectrogram side effect."""
+    import gomel_amd
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+
+    class STFT:
+        pass
+    s = STFT()
+    s.FrameShift, s.Window = hop, oracle.hann(N)
+    rng = np.random.default_rng(N + hop)
+    spec = rng.uniform(0.1, 2.0, size=(F, N)) * np.exp(2j * np.pi * rng.uniform(size=(F, N)))
+    x0 = oracle.x0_splitmix(3, N + (F - 1) * hop)
+    ref_spec = spec.copy()
+    want = oracle.istft_griffin_lim(s.Window, hop, ref_spec, I, x0)
+    got = gomel_amd.ISTFT(s, [list(r) for r in spec], I, x0=x0)
+    assert rms(got - want) < 1e-5 * max(1.0, rms(want))
+    arr = spec.copy()
+    got2 = gomel_amd.ISTFT(s, arr, I, x0=x0)
+    assert rms(got2 - want) < 1e-9 * max(1.0, rms(want))
+    assert np.max(np.abs(arr - ref_spec)) < 1e-9 * np.max(np.abs(ref_spec))

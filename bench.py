@@ -533,7 +533,7 @@ def main():
 
     if side:
         guarded("side_measurements", side_legs)
-    if solo:                                                          # float32 host I/O (half the PCIe bytes): informational, any workload
+    if solo and not args.no_single:                                   # float32 host I/O (half the PCIe bytes): informational, any workload
         def f32_leg():
             el_f, _, _, _ = host_to_host(engine, fields, min(n_utt, BLOCK), frames, first, 3, 1, lambda: None, io32=True)
             return min(n_utt, BLOCK) * frames * 3 / el_f

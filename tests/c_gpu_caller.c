@@ -60,6 +60,29 @@ int main(int argc, char** argv) {
     rc = gomel_from_mel_batch(h, n_utt, mel_ptrs, lens, x0_ptrs, NULL, outs, NULL);
     if (rc != GOMEL_OK) FAIL(rc, "gomel_from_mel_batch");
 
+    /* Calls in flight: the same call submitted twice as jobs (gomel_from_mel_batch_submit), waited for in reverse order; a handle with a job
+     * outstanding refuses gomel_destroy; both jobs deliver the synchronous call's bytes (a call this small runs inside submit). */
+    {
+        gomel_job *j1 = NULL, *j2 = NULL;
+        double **o1 = (double**)malloc(n_utt * sizeof *o1), **o2 = (double**)malloc(n_utt * sizeof *o2);
+        int fin = 0;
+        if (!o1 || !o2) return 2;
+        for (u = 0; u < n_utt; u++) { o1[u] = (double*)calloc(L, sizeof(double)); o2[u] = (double*)calloc(L, sizeof(double)); if (!o1[u] || !o2[u]) return 2; }
+        rc = gomel_from_mel_batch_submit(h, n_utt, mel_ptrs, lens, x0_ptrs, NULL, o1, NULL, &j1);
+        if (rc != GOMEL_OK || !j1) FAIL(rc, "gomel_from_mel_batch_submit (1)");
+        rc = gomel_from_mel_batch_submit(h, n_utt, mel_ptrs, lens, x0_ptrs, NULL, o2, NULL, &j2);
+        if (rc != GOMEL_OK || !j2) FAIL(rc, "gomel_from_mel_batch_submit (2)");
+        if (gomel_destroy(h) != GOMEL_ERR_NULL) FAIL(GOMEL_ERR_NULL, "gomel_destroy with jobs outstanding must be refused");
+        rc = gomel_job_wait(j2);
+        if (rc != GOMEL_OK) FAIL(rc, "gomel_job_wait (2)");
+        rc = gomel_job_poll(j1, &fin);
+        if (rc != GOMEL_OK) FAIL(rc, "gomel_job_poll");
+        rc = gomel_job_wait(j1);
+        if (rc != GOMEL_OK) FAIL(rc, "gomel_job_wait (1)");
+        for (u = 0; u < n_utt; u++)
+            if (memcmp(o1[u], outs[u], L * sizeof(double)) != 0 || memcmp(o2[u], outs[u], L * sizeof(double)) != 0) FAIL(GOMEL_ERR_BAD_CONFIG, "a job's waveform differs from the synchronous call's");
+    }
+
     /* the side effect of spectral_denormalize on the caller's slice (mel/mel.go:143, mel/impl.go:421-427): done by the shim, after the call */
     for (i = 0; i < n_pairs * 2; i++) mels[0][i] = exp(mels[0][i]);
 

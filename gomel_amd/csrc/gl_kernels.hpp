@@ -453,6 +453,7 @@ constexpr int kFusedThreads = 256;
 #define GL_WIN_B128 0
 #endif
 
+
 // The workgroup's tables (pass-1 / pass-2 twiddles, window) from global memory into LDS: 16 bytes per lane and instruction, EVERY load
 // issued before the first LDS write, so the fill costs one memory round trip (the element-wise loops it replaces went out in batches
 // of five 8-byte loads, each batch waited for).  A chunk-sized launch of a host-to-host call pays this once per 12.5 frames: -1 % on

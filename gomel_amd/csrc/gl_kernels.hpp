@@ -780,24 +780,40 @@ typedef unsigned long long v2ul __attribute__((ext_vector_type(2)));
 // MI355X_MICROARCH.md visibility section; a store's 16 bytes lie in one 128-byte line).
 GL_DEV bool persist_fresh_d(v4u q) { return q.y != kPersistSentinel && q.w != kPersistSentinel; }
 
+constexpr bool persist_d_tw1_in_lds(int n) { return n <= 2048; }
+template <int N> static constexpr size_t persist_d_lds_bytes() {
+    typedef Geo<N> G;
+    return ((size_t)(128 / G::T) * G::LDS_SLOTS + G::C + G::TW2_N + (persist_d_tw1_in_lds(N) ? G::TW1_N : 0)) * 16;
+}
 template <int N>
 __global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
                                                         const double* __restrict__ mag, const double* __restrict__ nyq, double* yw,
                                                         unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb) {
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = 128 / T, DEPTH = 4;
-    __shared__ v2d lds[STREAMS * G::LDS_SLOTS];
+    // LDS: the streams' exchange areas, then (round 4) the window and the pass-2 twiddles, which every iteration used to fetch from
+    // global memory anew -- 62 of its ~117 table loads; the pass-1 twiddles join them where two workgroups per CU still fit (N <= 2048)
+    extern __shared__ __attribute__((aligned(16))) char persist_d_smem[];
+    v2d* lds = reinterpret_cast<v2d*>(persist_d_smem);
+    v2d* win_l = lds + STREAMS * G::LDS_SLOTS;
+    v2d* tw2_l = win_l + G::C;
+    v2d* tw1_l = tw2_l + G::TW2_N;
+    constexpr bool TW1_LDS = persist_d_tw1_in_lds(N);
+    for (int i = threadIdx.x; i < G::C; i += 128) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
+    for (int i = threadIdx.x; i < G::TW2_N; i += 128) tw2_l[i] = tb.tw2d[i];
+    if constexpr (TW1_LDS) { for (int i = threadIdx.x; i < G::TW1_N; i += 128) tw1_l[i] = tb.tw1d[i]; }
+    __syncthreads();
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
     int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
     const bool live = frame < n_frames;
     if (!live) frame = n_frames - 1;
     v2d* my = lds + stream * G::LDS_SLOTS;
-    const Twiddles<v2d> tw{tb.tw1d, tb.tw2d, tb.wnd};
+    const Twiddles<v2d> tw{TW1_LDS ? (const v2d*)tw1_l : tb.tw1d, tw2_l, tb.wnd};
     auto sync = [] { __syncthreads(); };
     const UttDesc u = utts[frame_utt[frame]];
     const int f = (int)(frame - u.fbase), F = u.frames;
     const int nb = (N - 1) / hop;
-    const v2d* w2 = reinterpret_cast<const v2d*>(tb.windowd);
+    const v2d* w2 = win_l;
     int geo[16];   // per row j (pair t + T j, samples 2 (t + T j), +1): k0 | cnt << 20 (covering frames k0 .. k0 + cnt - 1)
 #pragma unroll
     for (int j = 0; j < 16; j++) {

@@ -749,7 +749,9 @@ template <int N, int OCC> static int persist_census_n(int device) {
 }
 template <int N> static int persist_census_d(int device) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist_d<N>, 128, 0) != hipSuccess ||
+    constexpr size_t lds = persist_d_lds_bytes<N>();
+    if ((lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gl_persist_d<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist_d<N>, 128, lds) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
@@ -1150,7 +1152,8 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                     HIPCHK(hipMemsetAsync(b->d_yw, 0xff, buf_doubles * 4, s));
                 }
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
-                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
+                // (dynamic LDS: exchange areas + window + twiddles; the size limit was raised -- and the census taken with it -- in persist_census_d)
+                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3((unsigned)b->n_wg), dim3(128), persist_d_lds_bytes<NN>(), s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
                                                        b->d_ywd, b->d_ctl, b->total_frames, I64, c.window, h->persist_ticks, h->persist_nap, h->dt));
                 if (b->pmix_k) {
                     // x_k = the overlap-add of the fp64 launch's last frames (k_ola's order), rounded to fp32 once; then the remaining

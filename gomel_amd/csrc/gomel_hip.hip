@@ -774,9 +774,12 @@ static int persist_census(gomel_handle* h, int occ) {   // occ 1 / 2: the fp32 k
 // ceil((16-SH)/SH) frames one after the other, so a launch never takes less than gmin frame latencies, while the generic kernels
 // run every frame in parallel: measured crossovers for gmin = 3 (scripts/cross_probe2.py, 60 iterations, one launch per
 // iteration): 1.5 k frames at N 4096, 2.5 k at 2048, 3 k at 1024, 6 k at 512, 12 k at 256; scaled with gmin.
-static int64_t fused_min_frames(const gomel_config& c) {
+// With fp64 iterations in the call the crossover at N 4096 lies higher (scripts/size_sweep.py, profiles/r04/size_sweep_T.txt: 1 710 frames
+// take 3.28 ms fused against 3.21 ms generic in the default mode, 4.19 against 3.88 in 64-bit mode; equal at ~2 000 frames): the fp64 fused
+// kernel's one-wave-per-SIMD streams walk their minimum of frames at 6.8 us each.  The smaller lengths cross where the fp32 kernels do.
+static int64_t fused_min_frames(const gomel_config& c, bool fp64_iterations = false) {
     if (!fused_kind(c)) return INT64_MAX;
-    const int64_t base = c.resolut >= 4096 ? 1536 : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288;
+    const int64_t base = c.resolut >= 4096 ? (fp64_iterations ? 2048 : 1536) : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288;
     return base * std::max(1, fused_gmin(c)) / 3;
 }
 
@@ -1608,7 +1611,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     }
     const int kind = fused_kind(c);   // (0 for generic lengths)
     b->fast = (!b->persist && !b->want_spec && h->path_mode != 1 && h->path_mode != 3 && kind &&
-               (h->path_mode == 2 || b->total_frames >= fused_min_frames(c))) ? kind : 0;
+               (h->path_mode == 2 || b->total_frames >= fused_min_frames(c, k64 > 0))) ? kind : 0;
     if (h->path_mode == 3 && !b->persist) return GOMEL_ERR_BAD_CONFIG;   // the persistent kernel was required and this batch does not fit it
     // Precision schedule: on the fused kernel's batches and (pmix_k, above) on the persistent kernel's.  What the generic kernels take
     // (a handful of utterances that fit neither) and the generic lengths stay fp64 for the whole call: correct, and cheap at that size.
@@ -2029,7 +2032,7 @@ static bool whole_batch_pays(const gomel_handle* h, size_t n_utt, const size_t* 
     if (!fused_applicable(h->cfg) || h->path_mode == 1 || h->path_mode == 3) return false;
     int64_t frames = 0;
     for (size_t u = 0; u < n_utt; u++) frames += (int64_t)(n_pairs[u] / (size_t)h->cfg.num_mels);
-    return frames >= 2 * fused_min_frames(h->cfg);   // below that a call is a handful of launches: nothing to pipeline
+    return frames >= 2 * fused_min_frames(h->cfg, resolve_fp64_iterations(h, h->cfg.griffin_lim_iterations) > 0);   // below that a call is a handful of launches: nothing to pipeline
 }
 
 static int submit_guarded(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,

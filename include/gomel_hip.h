@@ -227,7 +227,7 @@ int gomel_set_path(gomel_handle* h, int mode);
  *      a knob ends within 1e-4 RMS of the reference's float64 arithmetic on every utterance of the calibration sets (below) and on
  *      all but 1 of 126 976 held-out utterances at 60 iterations (4 of 540 672 at eleven other iteration counts): a rate of ~1e-5, not a guarantee (Griffin-Lim amplifies rounding without bound on a
  *      few inputs);
- *   32 fp32 kernels for every iteration: the opt-in FAST mode (1.4x the default's rate at 60 iterations).  Typically 1e-6 from the
+ *   32 fp32 kernels for every iteration: the opt-in FAST mode (1.7x the default's rate at 60 iterations).  Typically 1e-6 from the
  *      fp64 arithmetic, but ~1 % of 60-iteration utterances end beyond 1e-4;
  *   64 fp64 kernels for every iteration (~1e-13 from the fp64 restatement of the reference): the mode that is guaranteed on every input. */
 int gomel_set_precision(gomel_handle* h, int bits);

@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gomel_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "gl_fft.hpp"), os.path.join(HERE, "csrc", "gl_kernels.hpp"), os.path.join(HERE, "csrc", "gl_any.hpp"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "gl_fft.hpp"), os.path.join(HERE, "csrc", "gl_kernels.hpp"), os.path.join(HERE, "csrc", "gl_any.hpp"), os.path.join(HERE, "csrc", "gl_big.hpp"),
         os.path.join(HERE, "..", "include", "gomel_hip.h")]
 OUT = os.path.join(HERE, "libgomel_hip.so")
 

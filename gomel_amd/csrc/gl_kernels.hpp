@@ -1420,6 +1420,20 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
 // magnitudes, twiddles), all LDS dynamic (136 KB at N 4096: exchange areas + TW1 + TW2 + window in double), a lane's sample pair
 // is already 16 bytes (plain dwordx4 loads / stores, no DPP row pairing).  Algorithmic bytes per frame-iteration: twice the fp32
 // kernel's.  The fp64 vector unit runs at half the fp32 rate and packs nothing, so expect ~2.3x the fp32 time.
+// Build knobs of k_gl_fused_d / k_gl_fused_any_d (round 4).  The kernel allocates ALL 512 registers of its one wave per SIMD (256 + 246
+// AGPRs, to which the compiler sends global loads and parks what is live across the FFTs: ~260 v_accvgpr_read per frame, 12 % of its
+// vector instructions).  GL_D_WN_LDS=1 (default): a lane's eight W_N^k of the spectral step live in LDS (8 x T pairs, read per frame)
+// instead of 32 registers for the whole launch: 380 registers, ~100 fewer AGPR reads per frame, -2.2 % at N 4096, -1.8 % at 2048, -5.4 %
+// at 1024.  GL_D_W1CARRY=0 (reads the pass-1 twiddles from LDS in both FFTs): +1.8 %, stays 1.  profiles/r04/ab_fp64_registers.txt.
+#ifndef GL_D_W1CARRY
+#define GL_D_W1CARRY 1
+#endif
+#ifndef GL_D_WN_LDS
+#define GL_D_WN_LDS 1
+#endif
+#ifndef GL_D_WN_LDS_MINN
+#define GL_D_WN_LDS_MINN 256
+#endif
 struct MagRawD { double a[16]; double nq; };
 template <class G> GL_DEV void load_mag_rows_d(MagRawD& r, int t, const double* __restrict__ mag_row) {
 #pragma unroll
@@ -1445,9 +1459,17 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     v2d* tw1_l = lds + STREAMS * G::LDS_SLOTS;
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
-    int* g_sh = reinterpret_cast<int*>(win_l + G::C);
+    constexpr bool WN_LDS = GL_D_WN_LDS && N >= GL_D_WN_LDS_MINN;
+    v2d* wn_l = win_l + G::C;                                  // [8][T] (WN_LDS only)
+    int* g_sh = reinterpret_cast<int*>(wn_l + (WN_LDS ? 8 * T : 0));
     unsigned* cnt_sh = reinterpret_cast<unsigned*>(g_sh + STREAMS);   // [STREAMS][2]: one event counter per wave of a two-wave stream (N 4096)
     if constexpr (T > 64) { if (threadIdx.x < 2 * STREAMS) cnt_sh[threadIdx.x] = 0u; }
+    if constexpr (WN_LDS) {
+        if (threadIdx.x < T) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) wn_l[s8 * T + threadIdx.x] = tb.wnd[slot_bin<G>(threadIdx.x, s8)];
+        }
+    }
     for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
     for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
@@ -1497,7 +1519,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     }
     v2d xin[16], acc[KEEP], wn[8];
     const v2d* wl = win_l + t;
-    load_wn<G>(wn, t, tb.wnd);   // (rebuilt per frame from one table value, as make_wn does for the fp32 kernel: +3 % vector instructions here)
+    if constexpr (!WN_LDS) load_wn<G>(wn, t, tb.wnd);   // (rebuilt per frame from one table value, as make_wn does for the fp32 kernel: +3 % vector instructions here)
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         v2d a = xin_p[T * j + t];
@@ -1511,7 +1533,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     // One pass-1 twiddle read per frame at N 4096: the 15 values the inverse FFT reads at its end serve the next frame's forward FFT,
     // which starts a few hundred instructions later (15 of a frame's ~156 LDS reads; +1.6 % vector instructions for the registers
     // that cross the back edge; measured -1.2 % at N 4096, +1.7 % at N 1024 -- there the table is read twice, profiles/r03/ab_fp64_w1carry.txt)
-    constexpr bool W1CARRY = N >= 4096;
+    constexpr bool W1CARRY = GL_D_W1CARRY && N >= 4096;
     v2d w1c[16];
     if constexpr (W1CARRY) {
 #pragma unroll
@@ -1557,6 +1579,10 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
+            if constexpr (WN_LDS) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) wn[s8] = wn_l[s8 * T + t];
+            }
             spectral_apply<G>(v, t, mr, wn);
         }
         { NoStamps nst; fft_inverse<G>(v, my, t, tw, sync, nst, W1CARRY ? w1c : nullptr); }
@@ -1613,7 +1639,15 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     v2d* tw1_l = lds + STREAMS * G::LDS_SLOTS;
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
-    int* g_sh = reinterpret_cast<int*>(win_l + G::C);
+    constexpr bool WN_LDS = GL_D_WN_LDS && N >= GL_D_WN_LDS_MINN;
+    v2d* wn_l = win_l + G::C;                                  // [8][T] (WN_LDS: a lane's eight W_N^k, read per frame -- k_gl_fused_d)
+    int* g_sh = reinterpret_cast<int*>(wn_l + (WN_LDS ? 8 * T : 0));
+    if constexpr (WN_LDS) {
+        if (threadIdx.x < T) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) wn_l[s8 * T + threadIdx.x] = tb.wnd[slot_bin<G>(threadIdx.x, s8)];
+        }
+    }
     for (int i = threadIdx.x; i < G::TW1_N; i += kFusedThreads) tw1_l[i] = tb.tw1d[i];
     for (int i = threadIdx.x; i < G::TW2_N; i += kFusedThreads) tw2_l[i] = tb.tw2d[i];
     for (int i = threadIdx.x; i < G::C; i += kFusedThreads) win_l[i] = reinterpret_cast<const v2d*>(tb.windowd)[i];
@@ -1663,7 +1697,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
     }
     v2d xin[16], acc[16], wn[8];
     const v2d* wl = win_l + t;
-    load_wn<G>(wn, t, tb.wnd);
+    if constexpr (!WN_LDS) load_wn<G>(wn, t, tb.wnd);
 #pragma unroll
     for (int j = 0; j < 16; j++) {   // the first frame's window (x is complete: the tails of the previous iteration have been folded in)
         if constexpr (ODD) xin[j] = *reinterpret_cast<const v2d_a8*>(xin_f + 2 * (t + T * j));
@@ -1713,6 +1747,10 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
+            if constexpr (WN_LDS) {
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) wn[s8] = wn_l[s8 * T + t];
+            }
             spectral_apply<G>(v, t, mr, wn);
         }
         fft_inverse<G>(v, my, t, tw, sync);
@@ -1770,7 +1808,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
 }
 template <int N> static constexpr size_t fused_d_lds_bytes() {
     typedef Geo<N> G;
-    return ((size_t)(kFusedThreads / G::T) * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C) * 16 + (size_t)(kFusedThreads / G::T) * 12 + 16;   // + g_sh[STREAMS] + the event counters [STREAMS][2]
+    return ((size_t)(kFusedThreads / G::T) * G::LDS_SLOTS + G::TW1_N + G::TW2_N + G::C + ((GL_D_WN_LDS && N >= GL_D_WN_LDS_MINN) ? 8 * G::T : 0)) * 16 + (size_t)(kFusedThreads / G::T) * 12 + 16;   // + g_sh[STREAMS] + the event counters [STREAMS][2]
 }
 // out = x + tails, both fp64 (the fp64 fused path's last step)
 __global__ __launch_bounds__(256) void k_add_tails_d(const SegDesc* __restrict__ segs, const double* __restrict__ tail, double* __restrict__ out,

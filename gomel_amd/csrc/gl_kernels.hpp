@@ -808,7 +808,16 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restric
     const bool live = frame < n_frames;
     if (!live) frame = n_frames - 1;
     v2d* my = lds + stream * G::LDS_SLOTS;
-    const Twiddles<v2d> tw{TW1_LDS ? (const v2d*)tw1_l : tb.tw1d, tw2_l, tb.wnd};
+    // N 4096 (pass-1 twiddles not in LDS): a lane's fifteen pass-1 twiddles are the same in every iteration -- this workgroup keeps its
+    // frame -- so they are fetched once, not 2 x 15 times per iteration from L2 at the head of the forward and the tail of the inverse FFT
+    v2d w1c[16];
+    if constexpr (!TW1_LDS) {
+#pragma unroll
+        for (int uu = 0; uu < G::NB1; uu++)
+#pragma unroll
+            for (int q = 1; q < G::R1; q++) w1c[uu + G::NB1 * q] = tb.tw1d[q * G::C1 + (int)(threadIdx.x % T) + T * uu];
+    }
+    const Twiddles<v2d> tw{TW1_LDS ? (const v2d*)tw1_l : tb.tw1d, tw2_l, tb.wnd, TW1_LDS ? nullptr : w1c, TW1_LDS ? 0 : G::R1 - 1, nullptr};
     auto sync = [] { __syncthreads(); };
     const UttDesc u = utts[frame_utt[frame]];
     const int f = (int)(frame - u.fbase), F = u.frames;

@@ -504,34 +504,29 @@ template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* 
 
 // ---------------------------------------------------------------------------------------------- spectral step
 // Lane t's eight bin pairs after fft_forward: slot s pairs bin kA = t + B3*s (v[s]) with C - kA (v[15 - s]).
-// Lane 0 is special (its butterflies are self-mirrored); it is permuted into the same slot shape:
-//   slots 1..3 -> (VA[s], VA[8-s]), slots 4..7 -> (VB[s-4], VB[11-s]), slot 0 -> the self-paired bin C/2 (VA[4], VA[4]);
-// DC and Nyquist (both in VA[0]) are handled apart.
+// Lane 0 is special: its butterflies are self-mirrored -- VA[r] = Z[B3 r] pairs with VA[8-r], VB[r] = Z[B3/2 + B3 r] with VB[7-r].  It is
+// brought into the same slot shape by the CHEAPEST permutation (round 4: eight register moves in one chain instead of thirteen plus
+// temporaries -- the moves are issued for the whole wave, ~80 -> ~35 instructions per frame in the fp64 kernel):
+//   slots 0..3 -> (VB[s], VB[7-s])   v[15-s] already holds VB[7-s];  v[s]    <- v[8+s]
+//   slot  4    -> (VA4, VA4)         the self-paired bin C/2;        v[11]   <- v[4]
+//   slots 5..7 -> (VA[s], VA[8-s])   v[s] already holds VA[s];       v[15-s] <- v[8-s]
+// DC and Nyquist (both in VA[0] = v[0], saved by the caller) are handled apart.
 template <class G> GL_DEV int slot_bin(int t, int s) {
     if (t) return t + G::B3 * s;
-    return s == 0 ? G::C / 2 : (s < 4 ? G::B3 * s : G::B3 / 2 + G::B3 * (s - 4));
+    return s < 4 ? G::B3 / 2 + G::B3 * s : G::B3 * s;
 }
 
 template <class G, class V> GL_DEV void lane0_permute(V (&v)[16], bool is0) {
-    // (PA | PB) <- (VA | VB):  PA = [VA4 VA1 VA2 VA3 VB0 VB1 VB2 VB3], PB = [VB4 VB5 VB6 VB7 VA5 VA6 VA7 VA4]
-    if (is0) {
-        V a[8], b[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { a[i] = v[i]; b[i] = v[8 + i]; }
-        v[0] = a[4]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-        v[8] = b[4]; v[9] = b[5]; v[10] = b[6]; v[11] = b[7]; v[12] = a[5]; v[13] = a[6]; v[14] = a[7]; v[15] = a[4];
+    if (is0) {   // a chain, v[0] (DC / Nyquist) is the caller's by now: no temporaries
+        v[0] = v[8]; v[8] = v[1]; v[1] = v[9]; v[9] = v[2]; v[2] = v[10]; v[10] = v[3]; v[3] = v[11]; v[11] = v[4];
     }
 }
 template <class G, class V> GL_DEV void lane0_unpermute(V (&v)[16], bool is0, V dc) {
     if (is0) {
         // one lane in 2 T needs this: keep it a real branch (waves without a lane 0 skip it, the others run it with one lane
-        // enabled) instead of 28 full-width v_cndmask per frame -- the empty asm statement stops the if-conversion
+        // enabled) instead of full-width v_cndmask per frame -- the empty asm statement stops the if-conversion
         asm volatile("; lane 0 only" ::: );
-        V pa[8], pb[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { pa[i] = v[i]; pb[i] = v[8 + i]; }
-        v[0] = dc; v[4] = pa[0]; v[5] = pb[4]; v[6] = pb[5]; v[7] = pb[6];
-        v[8] = pa[4]; v[9] = pa[5]; v[10] = pa[6]; v[11] = pa[7]; v[12] = pb[0]; v[13] = pb[1]; v[14] = pb[2]; v[15] = pb[3];
+        v[11] = v[3]; v[3] = v[10]; v[10] = v[2]; v[2] = v[9]; v[9] = v[1]; v[1] = v[8]; v[8] = v[0]; v[0] = dc;   // (v[11] held the self-paired bin's second copy)
     }
 }
 
@@ -628,7 +623,7 @@ GL_DEV void clamp_pairs2(v2f& a0, v2f& b0, v2f w0, float ma0, float mb0, v2f& a1
 // Target magnitudes a lane needs for one frame.  A frame's row of N/2 magnitudes is stored in LANE-SLOT order
 // (mag_slot_index below): entry e of lane t sits at float (e/4 * T + t) * 4 + e%4, e < 8: mag[k_e(t)], e >= 8:
 // mag[C - k_{e-8}(t)] -- so a lane fetches everything with four coalesced 16-byte loads off one base pointer, issued
-// early so the HBM latency hides behind the forward FFT.  Lane 0's duplicate entry (slot 0 pairs bin C/2 with itself)
+// early so the HBM latency hides behind the forward FFT.  Lane 0's duplicate entry (slot 4 pairs bin C/2 with itself)
 // carries bin 0 (DC) instead.
 struct MagRegs {
     float ma[8], mb[8];
@@ -640,8 +635,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <class G> __host__ __device__ inline int mag_slot_index(int k) {
     const int r = k % G::B3, s = k / G::B3;
     int t, e;
-    if (r == 0) { t = 0; e = (k == 0) ? 8 : (s == 4 ? 0 : (s < 4 ? s : 8 + (8 - s))); }
-    else if (r == G::B3 / 2) { t = 0; e = (s < 4) ? 4 + s : 8 + 4 + (7 - s); }
+    if (r == 0) { t = 0; e = (k == 0) ? 8 + 4 : (s == 4 ? 4 : (s > 4 ? s : 8 + (8 - s))); }   // lane 0: DC rides in slot 4's duplicate entry, VA[s] s > 4 -> ma[s], VA[s] s < 4 -> mb[8-s]
+    else if (r == G::B3 / 2) { t = 0; e = (s < 4) ? s : 8 + (7 - s); }                          //         VB[s] s < 4 -> ma[s], s >= 4 -> mb[7-s]
     else if (r < G::B3 / 2) { t = r; e = s; }
     else { t = G::B3 - r; e = 8 + (7 - s); }
     return ((e / 4) * G::T + t) * 4 + (e % 4);
@@ -668,9 +663,9 @@ GL_DEV void finish_mags(MagRegs& m, const MagRaw& r, bool is0) {
     m.ma[4] = c1.x; m.ma[5] = c1.y; m.ma[6] = c1.z; m.ma[7] = c1.w;
     m.mb[0] = c2.x; m.mb[1] = c2.y; m.mb[2] = c2.z; m.mb[3] = c2.w;
     m.mb[4] = c3.x; m.mb[5] = c3.y; m.mb[6] = c3.z; m.mb[7] = c3.w;
-    m.m0 = is0 ? m.mb[0] : 0.f;
+    m.m0 = is0 ? m.mb[4] : 0.f;
     m.mn = is0 ? r.nq : 0.f;
-    m.mb[0] = is0 ? m.ma[0] : m.mb[0];
+    m.mb[4] = is0 ? m.ma[4] : m.mb[4];
 }
 template <class G> GL_DEV void load_mags(MagRegs& m, int t, const float* __restrict__ mag_row, const float* __restrict__ nyq) {
     MagRaw r;
@@ -697,7 +692,7 @@ template <class G, class V> GL_DEV void make_wn(V (&w)[8], int t, V wt) {
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         V g = twc<false>(wt, c16[s], s16[s]);  // wt * W_16^s
-        V z = s == 0 ? V{(S)0, (S)-1} : (s < 4 ? V{(S)c16[s], (S)-s16[s]} : V{(S)c32[s - 4], (S)-s32[s - 4]});
+        V z = s < 4 ? V{(S)c32[s], (S)-s32[s]} : (s == 4 ? V{(S)0, (S)-1} : V{(S)c16[s], (S)-s16[s]});   // W_N^{slot_bin(0, s)}
         w[s] = is0 ? z : g;
     }
 }
@@ -736,7 +731,7 @@ template <class G> GL_DEV void load_mags(MagRegsD& m, int t, const double* __res
         m.mb[e] = mag_row[(((8 + e) / 4) * G::T + t) * 4 + (e % 4)];
     }
     m.m0 = 0.0; m.mn = 0.0;
-    if (t == 0) { m.m0 = m.mb[0]; m.mb[0] = m.ma[0]; m.mn = nyq[0]; }
+    if (t == 0) { m.m0 = m.mb[4]; m.mb[4] = m.ma[4]; m.mn = nyq[0]; }
 }
 template <class G> GL_DEV void load_wn(v2d (&w)[8], int t, const v2d* __restrict__ wn) {
 #pragma unroll

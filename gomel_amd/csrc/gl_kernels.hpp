@@ -1451,9 +1451,9 @@ template <class G> GL_DEV void load_mag_rows_d(MagRawD& r, int t, const double* 
 GL_DEV void finish_mags_d(MagRegsD& m, const MagRawD& r, bool is0) {
 #pragma unroll
     for (int e = 0; e < 8; e++) { m.ma[e] = r.a[e]; m.mb[e] = r.a[8 + e]; }
-    m.m0 = is0 ? m.mb[0] : 0.0;
+    m.m0 = is0 ? m.mb[4] : 0.0;
     m.mn = is0 ? r.nq : 0.0;
-    m.mb[0] = is0 ? m.ma[0] : m.mb[0];
+    m.mb[4] = is0 ? m.ma[4] : m.mb[4];
 }
 
 template <int N, int SH>

@@ -363,3 +363,20 @@ def test_exported_istft_in_the_default_mode(oracle, N, hop, F, I, monkeypatch):
     got2 = gomel_amd.ISTFT(s, arr, I, x0=x0)
     assert rms(got2 - want) < 1e-9 * max(1.0, rms(want))
     assert np.max(np.abs(arr - ref_spec)) < 1e-9 * np.max(np.abs(ref_spec))
+
+
+def test_fused_threshold_follows_the_precision_mode(monkeypatch):
+    """At N 4096 the batch size from which the fused kernel beats the generic pair is higher when the call has fp64 iterations
+    (2048 frames against 1536: scripts/size_sweep.py): 5 x 342 frames run the generic kernels in the default and the 64-bit mode, the
+    fused kernel in the fast mode; 6 x 342 run the fused kernels in every mode."""
+    import gomel_amd
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    for sched, small, large in (("auto", 0, 1), (-1, 0, 1), (0, 1, 1)):
+        m = mel_obj(T, GriffinLimIterations=4)
+        eng = m.engine()
+        eng.set_precision_schedule(sched)
+        for U, want in ((5, small), (6, large)):
+            mels, seeds = inputs(U, 342, 192)
+            _, tm = run_batch(eng, mels, seeds)
+            assert tm["fast_path"] == want and tm["frames"] == U * 342, (sched, U, tm)
+        eng.close()

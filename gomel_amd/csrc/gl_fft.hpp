@@ -342,6 +342,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
     __builtin_amdgcn_sched_barrier(0);   // keep the twiddle reads above the butterfly: they land while it computes
     constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
     if constexpr (ILV) {
+        st.mark(0);
         sync_before_write(sync);
 #pragma unroll
         for (int u = 0; u < G::NB1; u++) {
@@ -387,6 +388,7 @@ template <class G, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v
     for (int u = 0; u < G::NB2; u++) dftR<false, G::R2, 1>(&v[u * G::R2]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ILV) {
+        st.mark(3);
         sync_before_write(sync);
 #pragma unroll
         for (int u = 0; u < G::NB2; u++) {

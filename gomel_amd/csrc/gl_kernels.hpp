@@ -1551,12 +1551,18 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
             for (int q = 0; q < G::R1; q++) w1c[u + G::NB1 * q] = tw1_l[q * G::C1 + t + T * u];
     }
 
+#ifdef GOMEL_STAMPS   // diagnostic build only (scripts/stamp_probe.py with GOMEL_FP64_ITERS=-1): the slots of k_gl_fused's table
+    Stamps st; st.start();
+#else
+    NoStamps st;
+#endif
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
         MagRawD mraw;                                                         // issued now, finished after the forward FFT
         load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
         mraw.nq = nyq_p[gg];
+        st.mark(16);
         // (k_gl_fused's single window read per frame was tried here too: 64 more live registers around the back edge, 3 % MORE
         // vector instructions through the AGPR traffic they cause -- the window is read twice)
         v2d v[16];
@@ -1579,11 +1585,12 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
                 fl[jj] = in_next ? 1.0 : 0.0;
             }
         }
+        st.mark(15);   // (window reads + multiply, slide, next rows' loads issued)
         if constexpr (W1CARRY) {
             const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr};
-            fft_forward<G>(v, my, t, twf, sync);
+            fft_forward<G>(v, my, t, twf, sync, st);
         } else {
-            fft_forward<G>(v, my, t, tw, sync);
+            fft_forward<G>(v, my, t, tw, sync, st);
         }
         {
             MagRegsD mr;
@@ -1594,7 +1601,8 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
             }
             spectral_apply<G>(v, t, mr, wn);
         }
-        { NoStamps nst; fft_inverse<G>(v, my, t, tw, sync, nst, W1CARRY ? w1c : nullptr); }
+        st.mark(7);
+        fft_inverse<G>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] = xl[jj];
         if (any_next) {
@@ -1604,6 +1612,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) asm volatile("" : "+v"(xin[KEEP + jj]));
         __builtin_amdgcn_sched_barrier(0);
+        st.mark(18);
         if (active) {
             v2d* xo = xout_p + T * (g * SH);
 #pragma unroll
@@ -1629,7 +1638,14 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
                 }
             }
         }
+        st.mark(14);
     }
+#ifdef GOMEL_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 20; k++) atomicAdd(&g_stamp_acc[k], st.acc[k]);
+        atomicAdd(&g_stamp_acc[20], (unsigned long long)g_max);
+    }
+#endif
 }
 // The any-hop form of the fp64 fused kernel: k_gl_fused_any's scheme (window and overlap-add accumulator shifted through the stream's
 // LDS area by hop samples per frame, tails folded into x behind every launch) on k_gl_fused_d's types, so that 64-bit mode keeps a

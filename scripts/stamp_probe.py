@@ -15,6 +15,8 @@ U, F, I = 256, 400, 6
 m = gomel_amd.NewMel()
 for k, v in dict(G, GriffinLimIterations=I).items(): setattr(m, k, v)
 e = m.engine(); e.set_path(2)
+if os.environ.get("GOMEL_FP64_ITERS"):   # -1: the fp64 fused kernel (its stamps use the same slots; in its interleaved passes slot 0 / 3 is the butterfly alone, slot 1 / 4 twiddles + writes + sync)
+    e.set_precision_schedule(int(os.environ["GOMEL_FP64_ITERS"]))
 base = np.random.default_rng(0).uniform(np.log(1e-5), np.log(50.0), size=(F * m.NumMels, 2))
 b = gomel_amd.Batch(e, [F * m.NumMels] * U); b.upload([base] * U, None, list(range(U)))
 L = _lib.lib()

@@ -774,12 +774,13 @@ static int persist_census(gomel_handle* h, int occ) {   // occ 1 / 2: the fp32 k
 // ceil((16-SH)/SH) frames one after the other, so a launch never takes less than gmin frame latencies, while the generic kernels
 // run every frame in parallel: measured crossovers for gmin = 3 (scripts/cross_probe2.py, 60 iterations, one launch per
 // iteration): 1.5 k frames at N 4096, 2.5 k at 2048, 3 k at 1024, 6 k at 512, 12 k at 256; scaled with gmin.
-// With fp64 iterations in the call the crossover at N 4096 lies higher (scripts/size_sweep.py, profiles/r04/size_sweep_T.txt: 1 710 frames
-// take 3.28 ms fused against 3.21 ms generic in the default mode, 4.19 against 3.88 in 64-bit mode; equal at ~2 000 frames): the fp64 fused
-// kernel's one-wave-per-SIMD streams walk their minimum of frames at 6.8 us each.  The smaller lengths cross where the fp32 kernels do.
+// With fp64 iterations in the call (default mode, 64-bit mode) the crossovers lie elsewhere (scripts/size_sweep.py GEOM 400 1|2 ..., profiles/r04/
+// size_sweep_paths.txt; default mode, 60 iterations): N 4096 ~2 000 frames, N 2048 / hop 256 ~4 200 (gmin 7: the fp64 fused launch is flat at
+// 3.1-3.3 ms up to a full round of 6 400 frames, the generic pair passes that at 4 000), N 1024 ~4 500, N 512 ~7 500, N 256 ~15 000.
 static int64_t fused_min_frames(const gomel_config& c, bool fp64_iterations = false) {
     if (!fused_kind(c)) return INT64_MAX;
-    const int64_t base = c.resolut >= 4096 ? (fp64_iterations ? 2048 : 1536) : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288;
+    const int64_t base = fp64_iterations ? (c.resolut >= 4096 ? 2048 : c.resolut == 2048 ? 1800 : c.resolut == 1024 ? 4500 : c.resolut == 512 ? 7500 : 15000)
+                                         : (c.resolut >= 4096 ? 1536 : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288);
     return base * std::max(1, fused_gmin(c)) / 3;
 }
 

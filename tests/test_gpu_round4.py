@@ -366,9 +366,9 @@ def test_exported_istft_in_the_default_mode(oracle, N, hop, F, I, monkeypatch):
 
 
 def test_fused_threshold_follows_the_precision_mode(monkeypatch):
-    """At N 4096 the batch size from which the fused kernel beats the generic pair is higher when the call has fp64 iterations
-    (2048 frames against 1536: scripts/size_sweep.py): 5 x 342 frames run the generic kernels in the default and the 64-bit mode, the
-    fused kernel in the fast mode; 6 x 342 run the fused kernels in every mode."""
+    """The batch size from which the fused kernel beats the generic pair depends on whether the call has fp64 iterations (N 4096: 2048
+    frames against 1536, scripts/size_sweep.py): 5 x 342 frames run the generic kernels in the default and the 64-bit mode, the
+    fused kernel in the fast mode; 6 x 342 run the fused kernels in every mode.  (N 2048 / hop 256: 4200 against 5973, N 1024: 4500 against 3072.)"""
     import gomel_amd
     monkeypatch.delenv("GOMEL_PRECISION", raising=False)
     for sched, small, large in (("auto", 0, 1), (-1, 0, 1), (0, 1, 1)):
@@ -380,3 +380,12 @@ def test_fused_threshold_follows_the_precision_mode(monkeypatch):
             _, tm = run_batch(eng, mels, seeds)
             assert tm["fast_path"] == want and tm["frames"] == U * 342, (sched, U, tm)
         eng.close()
+    for fields, frames, want_default, want_fast in ((S, 4000, 0, 1), (S, 4800, 1, 1), (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), 4800, 1, 0)):
+        for sched, want in (("auto", want_default), (0, want_fast)):
+            m = mel_obj(fields, GriffinLimIterations=4)
+            eng = m.engine()
+            eng.set_precision_schedule(sched)
+            mels, seeds = inputs(frames // 400, 400, fields["NumMels"])
+            _, tm = run_batch(eng, mels, seeds)
+            assert tm["fast_path"] == want, (fields["Resolut"], frames, sched, tm)
+            eng.close()

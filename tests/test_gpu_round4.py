@@ -380,7 +380,8 @@ def test_fused_threshold_follows_the_precision_mode(monkeypatch):
             _, tm = run_batch(eng, mels, seeds)
             assert tm["fast_path"] == want and tm["frames"] == U * 342, (sched, U, tm)
         eng.close()
-    for fields, frames, want_default, want_fast in ((S, 4000, 0, 1), (S, 4800, 1, 1), (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), 4800, 1, 0)):
+    for fields, frames, want_default, want_fast in ((S, 4000, 0, 2), (S, 4800, 1, 1),   # (2: 4000 frames of N 1024 still fit the fp32 persistent kernel)
+                                                    (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), 4800, 1, 0)):
         for sched, want in (("auto", want_default), (0, want_fast)):
             m = mel_obj(fields, GriffinLimIterations=4)
             eng = m.engine()

@@ -788,7 +788,10 @@ template <int N> static constexpr size_t persist_d_lds_bytes() {
 template <int N>
 __global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
                                                         const double* __restrict__ mag, const double* __restrict__ nyq, double* yw,
-                                                        unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb) {
+                                                        unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb,
+                                                        int64_t frame0, int64_t frame_end) {
+    // frame0 ... frame_end: the frames THIS launch iterates -- whole utterances (frames of an utterance exchange among themselves only); a batch
+    // of up to twice the chip's capacity runs as two such launches one after the other (round 4).  Offsets stay those of the whole batch.
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = 128 / T, DEPTH = 4;
     // LDS: the streams' exchange areas, then (round 4) the window and the pass-2 twiddles, which every iteration used to fetch from
@@ -804,9 +807,9 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restric
     if constexpr (TW1_LDS) { for (int i = threadIdx.x; i < G::TW1_N; i += 128) tw1_l[i] = tb.tw1d[i]; }
     __syncthreads();
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
-    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
-    const bool live = frame < n_frames;
-    if (!live) frame = n_frames - 1;
+    int64_t frame = frame0 + (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < frame_end;
+    if (!live) frame = frame_end - 1;
     v2d* my = lds + stream * G::LDS_SLOTS;
     // N 4096 (pass-1 twiddles not in LDS): a lane's fifteen pass-1 twiddles are the same in every iteration -- this workgroup keeps its
     // frame -- so they are fetched once, not 2 x 15 times per iteration from L2 at the head of the forward and the tail of the inverse FFT

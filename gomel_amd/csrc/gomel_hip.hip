@@ -678,6 +678,7 @@ struct gomel_batch {
     int persist = 0;
     int pmix_k = 0, pmix_occ = 0;   // > 0: precision schedule on the persistent path -- k_gl_persist_d for the first pmix_k iterations, then k_gl_persist<.., pmix_occ, ..> from its result
     int n_wg = 0;
+    std::vector<std::pair<int64_t, int64_t>> pgroups;   // k_gl_persist_d only: the frame ranges (whole utterances) of its launches -- one, or two for a batch of up to twice the chip's capacity
     int err_slot = -1;
     int persist_units = 0;     // share of the device this batch's queued persistent launch is accounted with (persist_take)
     hipEvent_t gate_ev = nullptr;   // recorded behind every run of this batch: how the device gate sees its work finish
@@ -1157,8 +1158,12 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                 }
                 if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
                 // (dynamic LDS: exchange areas + window + twiddles; the size limit was raised -- and the census taken with it -- in persist_census_d)
-                GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3((unsigned)b->n_wg), dim3(128), persist_d_lds_bytes<NN>(), s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
-                                                       b->d_ywd, b->d_ctl, b->total_frames, I64, c.window, h->persist_ticks, h->persist_nap, h->dt));
+                for (const std::pair<int64_t, int64_t>& gr : b->pgroups) {   // (one launch; two, one after the other, for a batch of up to twice the chip's capacity)
+                    const int spw_d = 128 / (N / 32);
+                    const unsigned grid = (unsigned)((gr.second - gr.first + spw_d - 1) / spw_d);
+                    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL(k_gl_persist_d<NN>, dim3(grid), dim3(128), persist_d_lds_bytes<NN>(), s, b->d_xd[0], b->d_utts, b->d_frame_utt, b->d_magd, b->d_nyqd,
+                                                           b->d_ywd, b->d_ctl, b->total_frames, I64, c.window, h->persist_ticks, h->persist_nap, h->dt, gr.first, gr.second));
+                }
                 if (b->pmix_k) {
                     // x_k = the overlap-add of the fp64 launch's last frames (k_ola's order), rounded to fp32 once; then the remaining
                     // iterations in the fp32 launch, and x_I = the overlap-add of ITS last frames.  A timeout in either launch sets the
@@ -1600,10 +1605,33 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         const bool room = h->batches_seen >= h->persist_retry_at && h->err_slab && !h->err_free.empty() && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20);
         if (room && !b->precise && n_wg <= persist_census(h, 2) && b->total_frames * (int64_t)N < ((int64_t)1 << 28))
             b->persist = n_wg <= persist_census(h, 1) ? 1 : 2;   // = the kernel's OCC: one wave per SIMD while the batch fits that way
-        else if (room && b->precise && n_wg <= persist_census(h, 3) && b->total_frames * (int64_t)N < ((int64_t)1 << 27)) {
-            b->persist = 3;                                       // 64-bit mode: k_gl_persist_d (three buffers of doubles: < 2^32 bytes)
-            // a precision schedule on this path too (round 4): the fp64 launch for the first k64 iterations, the fp32 launch for the rest
-            if (k64 > 0 && k64 < I && n_wg <= persist_census(h, 2)) { b->pmix_k = k64; b->pmix_occ = n_wg <= persist_census(h, 1) ? 1 : 2; }
+        else if (room && b->precise && b->total_frames * (int64_t)N < ((int64_t)1 << 27)) {
+            // 64-bit mode: k_gl_persist_d (three buffers of doubles: < 2^32 bytes).  Its census is half the fp32 kernel's (one wave per SIMD), so a
+            // batch of up to TWO chip-fulls runs as two launches one after the other, each over whole utterances (round 4: 2 x 342 frames at
+            // N 4096, 6-10 x 400 at N 1024 took the generic pair before, 1.25-1.3 x the time); more launches than two stop paying against the
+            // generic kernels, which run every frame of the batch in parallel.
+            const int64_t cap = (int64_t)persist_census(h, 3) * spw;
+            std::vector<std::pair<int64_t, int64_t>> groups;
+            bool fits = true;
+            int64_t g0 = 0, gf = 0;
+            for (const UttDesc& d : b->utts) {
+                if (d.frames > cap) { fits = false; break; }
+                if (gf + d.frames > cap) { groups.emplace_back(g0, g0 + gf); g0 += gf; gf = 0; }
+                gf += d.frames;
+            }
+            if (fits && gf) groups.emplace_back(g0, g0 + gf);
+            const bool mix = k64 > 0 && k64 < I;
+            // two launches only where the fp32 part of a schedule still runs as ONE launch of the fp32 kernel (or there is no fp32 part), and only
+            // at up to four covering frames per sample ((N-1)/hop <= 3: one round of gather loads per iteration) -- measured (scripts/size_sweep.py,
+            // profiles/r04/size_sweep_*.txt): N 4096 / hop 1280 2 x 342 frames 1.93 -> 1.47 ms, N 1024 / hop 256 2400-4000 frames 1.70-1.91 -> 1.33-1.49 ms,
+            // but N 2048 / hop 256 (eight covering frames) 1200-1600 frames 1.79-1.95 -> 1.85-2.00 ms: there the generic pair stays
+            const bool two_pay = (N - 1) / hop <= 3;
+            if (fits && (groups.size() == 1 || (groups.size() == 2 && two_pay && (!mix || n_wg <= persist_census(h, 2))))) {
+                b->persist = 3;
+                b->pgroups = groups;
+                // a precision schedule on this path too (round 4): the fp64 launch(es) for the first k64 iterations, the fp32 launch for the rest
+                if (mix && n_wg <= persist_census(h, 2)) { b->pmix_k = k64; b->pmix_occ = n_wg <= persist_census(h, 1) ? 1 : 2; }
+            }
         }
         if (b->persist) {
             b->n_wg = (int)n_wg;

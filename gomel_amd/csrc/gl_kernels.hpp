@@ -323,8 +323,11 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
 
 
 // fp64 ("precise") version of the generic frames kernel: same structure, double LDS / twiddles / window / magnitudes.
+#ifndef GL_FRAMES_D_WAVES
+#define GL_FRAMES_D_WAVES 2   // waves per SIMD asked of the compiler: 256 registers instead of the 264 it takes unasked -- four workgroups per CU instead of two
+#endif
 template <int N>
-__global__ __launch_bounds__(128) void k_gl_frames_d(const double* __restrict__ x, const int64_t* __restrict__ frame_xoff,
+__global__ __launch_bounds__(128, GL_FRAMES_D_WAVES) void k_gl_frames_d(const double* __restrict__ x, const int64_t* __restrict__ frame_xoff,
                                                      const double* __restrict__ mag, const double* __restrict__ nyq,
                                                      double* __restrict__ yw, int64_t n_frames, DevTables tb) {
     typedef Geo<N> G;

@@ -562,7 +562,10 @@ __device__ unsigned long long g_stamp_acc[21];
 template <int N, int OCC, int DEPTH>
 __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict__ x0, const UttDesc* __restrict__ utts, const int32_t* __restrict__ frame_utt,
                                                       const float* __restrict__ mag, const float* __restrict__ nyq, float* yw,
-                                                      unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb) {
+                                                      unsigned int* err, int64_t n_frames, int iters, int hop, unsigned spin_ticks, int retry_nap, DevTables tb,
+                                                      int64_t frame0, int64_t frame_end) {
+    // frame0 ... frame_end: the frames THIS launch iterates (whole utterances; a batch of up to two chip-fulls runs as two launches, round 4);
+    // offsets stay those of the whole batch
     typedef Geo<N> G;
     constexpr int T = G::T, STREAMS = 128 / T;
     // LEAN: the registers go to the gather (OCC 2: there are only 256; DEPTH 8: 64 quads in flight) -- twiddles, window, spectral
@@ -570,9 +573,9 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
     constexpr bool LEAN = OCC != 1 || DEPTH == 8;
     __shared__ v2f lds[STREAMS * G::LDS_SLOTS];
     const int stream = threadIdx.x / T, t = threadIdx.x % T;
-    int64_t frame = (int64_t)blockIdx.x * STREAMS + stream;
-    const bool live = frame < n_frames;
-    if (!live) frame = n_frames - 1;  // keeps the lanes in the barriers; nothing of it is stored
+    int64_t frame = frame0 + (int64_t)blockIdx.x * STREAMS + stream;
+    const bool live = frame < frame_end;
+    if (!live) frame = frame_end - 1;  // keeps the lanes in the barriers; nothing of it is stored
     v2f* my = lds + stream * G::LDS_SLOTS;
     // every twiddle operand of this lane in registers for the whole call (the launch runs one wave per SIMD: 512 VGPRs)
     v2f w2r[16], w1r[16];

@@ -1172,7 +1172,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
                     hipLaunchKernelGGL(k_narrow, dim3((unsigned)std::min<int64_t>((b->total_len / 4 + 255) / 256, 65536)), dim3(256), 0, s, b->d_xd[1], b->d_x[0], b->total_len);
 #define GOMEL_PERSIST_LAUNCH(OCC, DEPTH)                                                                                                                     \
     GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, OCC, DEPTH>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, \
-                                           b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I - I64, c.window, h->persist_ticks, h->persist_nap, h->dt))
+                                           b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I - I64, c.window, h->persist_ticks, h->persist_nap, h->dt, (int64_t)0, b->total_frames))
                     if (b->pmix_occ == 2) { GOMEL_PERSIST_LAUNCH(2, 2); } else { GOMEL_PERSIST_LAUNCH(1, 4); }
 #undef GOMEL_PERSIST_LAUNCH
                     if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
@@ -1254,10 +1254,14 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
             HIPCHK(hipMemsetAsync(b->d_yw, 0xff, buf_floats * 4, s));
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[0], s));
 #define GOMEL_PERSIST_LAUNCH(OCC, DEPTH)                                                                                                                     \
-    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, OCC, DEPTH>), dim3((unsigned)b->n_wg), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, \
-                                           b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt))
-            if (persist == 2) { GOMEL_PERSIST_LAUNCH(2, 2); }
-            else { GOMEL_PERSIST_LAUNCH(1, 4); }   // (eight covering frames in flight, for hops below N/4, measured slower than two rounds of four: its registers come out of the tables')
+    GOMEL_DISPATCH_N(N, hipLaunchKernelGGL((k_gl_persist<NN, OCC, DEPTH>), dim3(grid), dim3(128), 0, s, b->d_x[0], b->d_utts, b->d_frame_utt, b->d_mag, \
+                                           b->d_nyq, b->d_yw, b->d_ctl, b->total_frames, I, c.window, h->persist_ticks, h->persist_nap, h->dt, gr.first, gr.second))
+            for (const std::pair<int64_t, int64_t>& gr : b->pgroups) {   // (one launch; two, one after the other, for a batch of up to two chip-fulls)
+                const int spw_f = 128 / (N / 32);
+                const unsigned grid = (unsigned)((gr.second - gr.first + spw_f - 1) / spw_f);
+                if ((int)grid > persist_census(h, 1)) { GOMEL_PERSIST_LAUNCH(2, 2); }   // the kernel's OCC: one wave per SIMD while the launch fits that way
+                else { GOMEL_PERSIST_LAUNCH(1, 4); }   // (eight covering frames in flight, for hops below N/4, measured slower than two rounds of four: its registers come out of the tables')
+            }
 #undef GOMEL_PERSIST_LAUNCH
             if (tm) HIPCHK(hipEventRecord(b->dom_ev[1], s));
             const float* y_last = b->d_yw + (size_t)((I - 1) % 3) * buf_floats;
@@ -1603,23 +1607,35 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         int max_frames = 0;
         for (const UttDesc& d : b->utts) max_frames = std::max(max_frames, d.frames);
         const bool room = h->batches_seen >= h->persist_retry_at && h->err_slab && !h->err_free.empty() && b->max_len < ((int64_t)1 << 30) && max_frames < (1 << 20);
-        if (room && !b->precise && n_wg <= persist_census(h, 2) && b->total_frames * (int64_t)N < ((int64_t)1 << 28))
-            b->persist = n_wg <= persist_census(h, 1) ? 1 : 2;   // = the kernel's OCC: one wave per SIMD while the batch fits that way
-        else if (room && b->precise && b->total_frames * (int64_t)N < ((int64_t)1 << 27)) {
+        // utterances packed, in order, into launches of at most `cap` frames each (empty: some utterance does not fit a launch alone)
+        auto pack = [&](int64_t cap) {
+            std::vector<std::pair<int64_t, int64_t>> groups;
+            int64_t g0 = 0, gf = 0;
+            for (const UttDesc& d : b->utts) {
+                if (d.frames > cap) return std::vector<std::pair<int64_t, int64_t>>();
+                if (gf + d.frames > cap) { groups.emplace_back(g0, g0 + gf); g0 += gf; gf = 0; }
+                gf += d.frames;
+            }
+            if (gf) groups.emplace_back(g0, g0 + gf);
+            return groups;
+        };
+        if (room && !b->precise && b->total_frames * (int64_t)N < ((int64_t)1 << 28)) {
+            // fp32: one launch while the batch fits the chip (OCC 1 or 2); up to TWO chip-fulls as two launches one after the other, each over
+            // whole utterances (round 4: 3-4 x 342 frames at N 4096, 6-10 x 400 at N 2048 took the generic pair before)
+            // (two launches only at up to four covering frames per sample, as for the fp64 kernel below: N 4096 / hop 1280 3-4 x 342 frames 1.76-1.98 ->
+            // 1.37-1.60 ms, N 1024 / hop 256 4800-6400 frames 1.60-1.89 (fused) -> 1.39-1.69, but N 2048 / hop 256 2400-3200 frames 1.90-2.07 -> 1.95-2.25)
+            const std::vector<std::pair<int64_t, int64_t>> groups = pack((int64_t)persist_census(h, 2) * spw);
+            if (groups.size() == 1 || (groups.size() == 2 && (N - 1) / hop <= 3)) {
+                b->persist = (groups.size() == 1 && n_wg <= persist_census(h, 1)) ? 1 : 2;   // (what the census / the gate's share is taken with)
+                b->pgroups = groups;
+            }
+        } else if (room && b->precise && b->total_frames * (int64_t)N < ((int64_t)1 << 27)) {
             // 64-bit mode: k_gl_persist_d (three buffers of doubles: < 2^32 bytes).  Its census is half the fp32 kernel's (one wave per SIMD), so a
             // batch of up to TWO chip-fulls runs as two launches one after the other, each over whole utterances (round 4: 2 x 342 frames at
             // N 4096, 6-10 x 400 at N 1024 took the generic pair before, 1.25-1.3 x the time); more launches than two stop paying against the
             // generic kernels, which run every frame of the batch in parallel.
-            const int64_t cap = (int64_t)persist_census(h, 3) * spw;
-            std::vector<std::pair<int64_t, int64_t>> groups;
-            bool fits = true;
-            int64_t g0 = 0, gf = 0;
-            for (const UttDesc& d : b->utts) {
-                if (d.frames > cap) { fits = false; break; }
-                if (gf + d.frames > cap) { groups.emplace_back(g0, g0 + gf); g0 += gf; gf = 0; }
-                gf += d.frames;
-            }
-            if (fits && gf) groups.emplace_back(g0, g0 + gf);
+            const std::vector<std::pair<int64_t, int64_t>> groups = pack((int64_t)persist_census(h, 3) * spw);
+            const bool fits = !groups.empty();
             const bool mix = k64 > 0 && k64 < I;
             // two launches only where the fp32 part of a schedule still runs as ONE launch of the fp32 kernel (or there is no fp32 part), and only
             // at up to four covering frames per sample ((N-1)/hop <= 3: one round of gather loads per iteration) -- measured (scripts/size_sweep.py,

@@ -262,12 +262,13 @@ def test_every_fused_instantiation(oracle, N, SH):
 
 
 def test_automatic_path_choice(oracle):
-    """Library's choice: a short utterance runs the generic kernels (every frame in parallel), batches past the measured
-    crossover (1536 frames at N 4096 / hop 1280) the fused kernel; both agree with the oracle."""
+    """Library's choice: what fits the chip at once (or twice, as whole utterances) runs the persistent kernel, a long utterance below the
+    measured crossover (1536 frames at N 4096 / hop 1280) the generic kernels (every frame in parallel), batches past it the fused
+    kernel; all agree with the oracle."""
     import gomel_amd
     m = make_mel("T", 2)
     e = m.engine()
-    for n_utt, frames, want_fast in ((1, 300, 2), (4, 300, 0), (8, 300, 1)):   # 2 = the persistent kernel (tests/test_gpu_persist.py)
+    for n_utt, frames, want_fast in ((1, 300, 2), (4, 300, 2), (1, 1400, 0), (8, 300, 1)):   # 2 = the persistent kernel (tests/test_gpu_persist.py; 4 x 300: two launches)
         b = gomel_amd.Batch(e, [frames * 192] * n_utt)
         mels = [oracle.random_logmel(frames, 192, seed=u) for u in range(n_utt)]
         b.upload(mels, None, list(range(n_utt)))

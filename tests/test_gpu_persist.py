@@ -105,8 +105,9 @@ def test_towavpng_single_utterance_uses_it_and_matches_the_oracle(oracle):
 def test_batches_beyond_the_chip_fall_to_the_other_kernels(oracle):
     import gomel_amd
     m, e = engine(4096, 1280, 192, 3, 0, fmax=16000.0)
-    # 512 workgroups at one wave per SIMD, 1024 at two (the 256-VGPR build of the kernel); then generic up to the fused kernel's 1536
-    for n_utt, frames, want in ((1, 300, 2), (1, 512, 2), (2, 300, 2), (1, 1024, 2), (1, 1025, 0), (4, 300, 0), (8, 300, 1)):
+    # 512 workgroups at one wave per SIMD, 1024 at two (the 256-VGPR build of the kernel); up to two such launches over whole utterances
+    # (round 4: 4 x 300 = 900 + 300); then generic up to the fused kernel's 1536
+    for n_utt, frames, want in ((1, 300, 2), (1, 512, 2), (2, 300, 2), (1, 1024, 2), (1, 1025, 0), (4, 300, 2), (1, 1400, 0), (8, 300, 1)):
         b = gomel_amd.Batch(e, [frames * 192] * n_utt)
         b.upload(logmels(oracle, [frames] * n_utt, 192), None, list(range(n_utt)))
         assert b.run_timed()["fast_path"] == want, (n_utt, frames)

@@ -380,7 +380,7 @@ def test_fused_threshold_follows_the_precision_mode(monkeypatch):
             _, tm = run_batch(eng, mels, seeds)
             assert tm["fast_path"] == want and tm["frames"] == U * 342, (sched, U, tm)
         eng.close()
-    for fields, frames, want_default, want_fast in ((S, 4000, 2, 2), (S, 4800, 1, 1),   # (2: 4000 frames of N 1024 still fit the persistent kernels -- fp32: one launch; default: two fp64 launches + one fp32)
+    for fields, frames, want_default, want_fast in ((S, 4000, 2, 2), (S, 4800, 1, 2),   # (2: the persistent kernels -- 4000 frames of N 1024: fp32 one launch, default two fp64 launches + one fp32; 4800: fp32 two launches, default three would not pay: fused)
                                                     (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), 4800, 1, 0)):
         for sched, want in (("auto", want_default), (0, want_fast)):
             m = mel_obj(fields, GriffinLimIterations=4)

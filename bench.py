@@ -11,7 +11,7 @@ METRIC (SURVEY 8d / BASELINE.md): frames/s = frames pushed through all 60 Griffi
 gomel_from_mel_batch -- host fp64 log-mel in, host fp64 waveforms out, H2D and D2H INCLUDED, handle creation excluded.  A "step" is
 one such call over the rank's batch; W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, MAX
 over ranks.  `value` is the DEFAULT precision mode -- the handle as gomel_create hands it over, no knob turned: the calibrated
-fp64-then-fp32 schedule (gomel_auto_fp64_iterations: 35 + 25 iterations at 60), the mode that agrees with the reference's float64
+fp64-then-fp32 schedule (gomel_auto_fp64_iterations: 35 + 25 iterations at 60 for this geometry), the mode that agrees with the reference's float64
 arithmetic within 1e-4 RMS -- with TWO CALLS IN FLIGHT (gomel_from_mel_batch_submit / gomel_job_wait: every call one whole batch,
 the copies of one call beside the kernels of the other; two sets of output buffers).  Beside it: the same calls from a lone
 synchronous caller (`single_caller_frames_per_s`: the chunked call), the opt-in fp32 fast mode and fp64 throughout (`modes`), each

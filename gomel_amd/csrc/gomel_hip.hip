@@ -234,19 +234,27 @@ static int validate_config(const gomel_config* c) {
 // first 0.1 %, 35 none of the 24 576 -- but the tail never closes: single utterances amplify the rounding of the LAST fifteen iterations
 // a thousandfold (one of 24 576 beyond 1e-4 at k = 45 of 60), so a schedule bounds the RATE of such utterances, about 1 in 10^4 to 10^5
 // at these entries; only fp64 throughout excludes them.  Even two fp32 iterations leave 2 of 24 576 beyond 3e-5, hence k(2) = 1.
-// Between calibrated points k is interpolated upwards; beyond the last one the number of trailing fp32 iterations is held at its 20.
+// Between calibrated points k is interpolated upwards; beyond the last one the number of trailing fp32 iterations is held (20; 10 in the second table).
+// Geometries whose frames overlap six-fold or more (hop <= Resolut / 6; NewMel's defaults overlap eight-fold) have the heavier tail: a
+// larger held-out run (131 072 random spectrograms of the NewMel geometry at 60 iterations, profiles/r04/validation/val3_*) found 6 beyond
+// 1e-4 and 27 beyond 3e-5 at k = 35, 0 / 2 at 45, 0 / 0 at 50; at 20 iterations 1 / 9 of 65 536 at k = 10, 0 / 0 at 16; at 100 1 / 4 at 80,
+// 0 / 1 at 90 -- while 94 208 utterances of the towav geometry show none beyond 3e-5 at the first table's 35.  They take the second table.
 struct AutoPoint { int iters, k; };
-static const AutoPoint kAutoSchedule[] = {{2, 1}, {5, 3}, {10, 6}, {20, 10}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};   // profiles/r04/calibration/TABLE.txt
-static int auto_fp64_iterations(int I) {
+static const AutoPoint kAutoSchedule[] = {{2, 1}, {5, 3}, {10, 6}, {20, 10}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};        // profiles/r04/calibration/TABLE.txt
+static const AutoPoint kAutoScheduleDense[] = {{2, 1}, {5, 3}, {10, 6}, {20, 16}, {30, 25}, {40, 32}, {60, 50}, {100, 90}};   // profiles/r04/validation/val3_D_random_*
+static bool auto_dense(const gomel_config& c) { return c.window > 0 && (int64_t)c.window * 6 <= (int64_t)c.resolut; }
+static int auto_fp64_iterations(const gomel_config& c, int I) {
+    const AutoPoint* tab = auto_dense(c) ? kAutoScheduleDense : kAutoSchedule;
     constexpr int n = (int)(sizeof kAutoSchedule / sizeof kAutoSchedule[0]);
-    if (I <= kAutoSchedule[0].iters) return std::min(I, kAutoSchedule[0].k);
+    static_assert(sizeof kAutoSchedule == sizeof kAutoScheduleDense, "the two tables have the same calibrated iteration counts");
+    if (I <= tab[0].iters) return std::min(I, tab[0].k);
     for (int i = 1; i < n; i++)
-        if (I <= kAutoSchedule[i].iters) {
-            const AutoPoint a = kAutoSchedule[i - 1], b = kAutoSchedule[i];
+        if (I <= tab[i].iters) {
+            const AutoPoint a = tab[i - 1], b = tab[i];
             const int k = a.k + ((b.k - a.k) * (I - a.iters) + (b.iters - a.iters) - 1) / (b.iters - a.iters);   // rounded up
             return std::min(I, std::max(k, a.k));
         }
-    return I - (kAutoSchedule[n - 1].iters - kAutoSchedule[n - 1].k);
+    return I - (tab[n - 1].iters - tab[n - 1].k);
 }
 // fp64 iterations of a call of I iterations on this handle: 0 = fp32 throughout, >= I = fp64 throughout.  Caller holds h->mu.
 static int resolve_fp64_iterations(const gomel_handle* h, int I) {
@@ -255,7 +263,7 @@ static int resolve_fp64_iterations(const gomel_handle* h, int I) {
         case kPrecFp32: return 0;
         case kPrecFp64: return I;
         case kPrecSchedule: return std::min(I, std::max(0, h->precise_iters));
-        default: return auto_fp64_iterations(I);
+        default: return auto_fp64_iterations(h->cfg, I);
     }
 }
 
@@ -1498,7 +1506,7 @@ int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations) {
 int32_t gomel_auto_fp64_iterations(const gomel_config* cfg, int32_t iterations) {
     if (!cfg || iterations <= 0) return 0;
     if (!gomel_supported_n(cfg->resolut)) return iterations;   // generic-length kernels: fp64
-    return auto_fp64_iterations(iterations);
+    return auto_fp64_iterations(*cfg, iterations);
 }
 int gomel_get_precision(const gomel_handle* h, int32_t iterations, int32_t* fp64_iterations) {
     if (!h || !fp64_iterations) return GOMEL_ERR_NULL;

@@ -82,6 +82,15 @@ def test_automatic_precision_schedule_table(L):
     c = GomelConfig()
     L.gomel_default_config(ctypes.byref(c))
     k = lambda i: L.gomel_auto_fp64_iterations(ctypes.byref(c), i)
+    # NewMel's defaults (Resolut 2048 / hop 256) overlap eight-fold: geometries with hop <= Resolut / 6 take the second table (the larger
+    # held-out runs of profiles/r04/validation/val3_*: 6 of 131 072 beyond 1e-4 at 35 of 60, none beyond 3e-5 at 50)
+    dense = {2: 1, 5: 3, 10: 6, 20: 16, 30: 25, 40: 32, 60: 50, 100: 90}
+    assert [k(i) for i in sorted(dense)] == [dense[i] for i in sorted(dense)] and k(300) == 290 and k(50) == 41
+    c.window = 342                                                        # just above Resolut / 6: the first table
+    assert k(60) == 35
+    c.window = 341
+    assert k(60) == 50
+    c.resolut, c.window = 4096, 1280                                      # the towav geometry: the first table
     table = {2: 1, 5: 3, 10: 6, 20: 10, 30: 25, 40: 30, 60: 35, 100: 80}
     txt = open(os.path.join(ROOT, "profiles", "r04", "calibration", "TABLE.txt")).read()
     committed = eval(re.search(r"beyond 3e-5 in any set: (\{.*\})", txt).group(1))
@@ -94,6 +103,7 @@ def test_automatic_precision_schedule_table(L):
     for n in (1000, 4095, 8192):
         c.resolut = n
         assert k(60) == 60
+    c.resolut = 4096
     assert SCHEDULE_AUTO == -2 ** 31
     src = open(os.path.join(ROOT, "include", "gomel_hip.h")).read()
     assert "#define GOMEL_SCHEDULE_AUTO (-2147483647 - 1)" in src

@@ -4,7 +4,7 @@ BLOCKS x 256 utterances of 400 frames.  Errors are taken on the device (waveform
 
 usage: calibrate_schedule.py GEOM CLASS BLOCKS [I:k,k,k ...]
   GEOM  T (N 4096 / hop 1280 / 192 mels, towav), S (N 1024 / hop 256 / 80 mels, TTS), D (NewMel defaults: N 2048 / hop 256 / 160 mels)
-  CLASS random (iid U[ln 1e-5, ln 50] log-mel, bench.py's inputs) | signal (synthetic audio through ToMel)
+  CLASS random (iid U[ln 1e-5, ln 50] log-mel, bench.py's inputs) | random0 (the same, lowest band and bin N/2 silent) | signal (synthetic audio through ToMel)
 One line per (I, k): count, median, p99, p99.9, max, utterances over 1e-4 / 3e-5 / 1e-5.
 """
 import math
@@ -68,8 +68,14 @@ def main():
 
     def make_block(blk):
         first = SEED0 + blk * U
-        if cls == "random":
-            return [np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
+        if cls in ("random", "random0"):
+            ms = [np.random.default_rng(first + u).uniform(math.log(1e-5), math.log(50.0), size=(F * K, 2)) for u in range(U)]
+            if cls == "random0":      # the same with a silent lowest band (bin 0's magnitude) and a silent bin N/2: the two REAL bins, whose clamp is a sign decision
+                for a in ms:
+                    v = a.reshape(F, K, 2)
+                    v[:, 0, :] = math.log(1e-5)
+                    v[:, K - 1, 1] = math.log(1e-5)
+            return ms
         x = signals(first, N + (F - 1) * hop, sr, dev).cpu().numpy()
         return m0.engine().to_mel_batch([x[u] for u in range(U)])
     stream = len(grid) == 1                             # one iteration count: blocks are made as they are used (any number of them)

@@ -225,7 +225,7 @@ int gomel_set_path(gomel_handle* h, int mode);
 /* Arithmetic of the Griffin-Lim iterations (mel/mel.go:85-136 is float64 / complex128 throughout) for batches created afterwards:
  *   0  (default) AUTOMATIC: the calibrated precision schedule gomel_auto_fp64_iterations(cfg, I) -- the call a caller gets without
  *      a knob ends within 1e-4 RMS of the reference's float64 arithmetic on every utterance of the calibration sets (below) and on
- *      all but 8 of 372 736 held-out utterances at 60 iterations (none of 94 208 at the towav geometry; 6 of 131 072 random and 2 of 81 920 signal-derived spectrograms at the NewMel-default geometry; 4 of 540 672 at eleven other iteration counts): a rate of 1e-5 ... 5e-5, not a guarantee (Griffin-Lim amplifies rounding without bound on a
+ *      all but 1 of 536 576 held-out random spectrograms at 60 iterations (towav geometry 0 of 225 280, TTS geometry 1 of 180 224, NewMel-default geometry 0 of 131 072 with its second table below; 4 of 540 672 at eleven other iteration counts with the first table): a rate below 1e-5, not a guarantee (Griffin-Lim amplifies rounding without bound on a
  *      few inputs);
  *   32 fp32 kernels for every iteration: the opt-in FAST mode (1.7x the default's rate at 60 iterations).  Typically 1e-6 from the
  *      fp64 arithmetic, but ~1 % of 60-iteration utterances end beyond 1e-4;

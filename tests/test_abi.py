@@ -91,10 +91,11 @@ def test_automatic_precision_schedule_table(L):
     c.window = 341
     assert k(60) == 50
     c.resolut, c.window = 4096, 1280                                      # the towav geometry: the first table
-    table = {2: 1, 5: 3, 10: 6, 20: 10, 30: 25, 40: 30, 60: 35, 100: 80}
+    table = {2: 1, 5: 3, 10: 6, 20: 14, 30: 25, 40: 30, 60: 35, 100: 80}
     txt = open(os.path.join(ROOT, "profiles", "r04", "calibration", "TABLE.txt")).read()
     committed = eval(re.search(r"beyond 3e-5 in any set: (\{.*\})", txt).group(1))
-    assert committed == table                                             # the code's points ARE the committed calibration's
+    assert committed == {**table, 20: 10}                           # the code's points ARE the committed calibration's, but for 20 iterations:
+    # 65 536 held-out TTS-geometry spectrograms left 4 beyond 1e-4 at the calibration's 10, 1 at 14 (profiles/r04/validation/val3_S_random_65536_otherI.txt)
     assert [k(i) for i in sorted(table)] == [table[i] for i in sorted(table)]
     assert k(0) == 0 and k(-3) == 0 and k(1) == 1 and L.gomel_auto_fp64_iterations(None, 60) == 0
     ks = [k(i) for i in range(0, 400)]

@@ -1568,7 +1568,7 @@ int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.g
 
 // One plan for both kinds of input: log-mel pairs (n_pairs[u] = frames * NumMels) or, for gomel_istft, linear magnitudes
 // (`direct`: n_pairs[u] = frames, rows of N/2+1 doubles).  `iters` >= 0 overrides the configured iteration count.
-enum { BF_DIRECT = 1, BF_IO32 = 2, BF_SPEC = 4 };   // batch_create_common flags
+enum { BF_DIRECT = 1, BF_IO32 = 2, BF_SPEC = 4, BF_NOPERSIST = 8 };   // batch_create_common flags (NOPERSIST: a submitted job -- a persistent launch wants a verifying wait)
 // init_stream: where the batch's descriptor copies and zero-fills are queued -- the stream its upload will use (every reader waits for
 // the upload): the handle's compute stream for the batch API, the upload stream inside the chunk pipeline, where anything queued on
 // the compute stream would sit (and, coming from pageable memory, hold the host) behind the previous chunks' kernels.
@@ -1613,7 +1613,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
     // covering frames that traffic costs more than the launches it saves -- measured at N 2048: hop 256 0.76 ms against 1.05 ms
     // generic, hop 128 1.25 against 1.14 -- so the library picks the kernel down to hop = N/8 only; gomel_set_path(h, 3) still runs it)
     const bool persist_pays = (N - 1) / hop <= kPersistAutoNb || h->path_mode == 3;
-    if (!h->generic && !b->want_spec && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && persist_pays && I >= 2) {
+    if (!h->generic && !b->want_spec && !(flags & BF_NOPERSIST) && (h->path_mode == 0 || h->path_mode == 3) && persist_geometry_ok(c) && persist_pays && I >= 2) {
         const int spw = 128 / (N / 32);                                  // streams (frames) per workgroup
         const int64_t n_wg = (b->total_frames + spw - 1) / spw;
         int max_frames = 0;
@@ -2115,8 +2115,9 @@ static int submit_guarded(gomel_handle* h, size_t n_utt, const void* const* mel,
         *job_out = j;
         return GOMEL_OK;
     }
-    int rc = batch_create_common(h, n_utt, n_pairs, io32 ? BF_IO32 : 0, -1, &j->b, h->up_stream);
-    if (!rc && j->b->persist) rc = GOMEL_ERR_BAD_CONFIG;   // (cannot happen above the fused threshold; a persistent launch wants a verifying wait)
+    int rc = batch_create_common(h, n_utt, n_pairs, (io32 ? BF_IO32 : 0) | BF_NOPERSIST, -1, &j->b, h->up_stream);   // (since two-launch persistent batches reach above the
+    // fused kernels' threshold at the small frame lengths, the job says so itself: whole-batch fused / generic launches only)
+    if (!rc && j->b->persist) rc = GOMEL_ERR_BAD_CONFIG;
     bool queued = false;
     if (!rc) {
         std::lock_guard<std::mutex> lk(h->mu);

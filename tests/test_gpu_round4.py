@@ -340,6 +340,27 @@ def test_float_host_buffers_as_jobs(oracle, monkeypatch):
     eng.close()
 
 
+def test_jobs_of_a_size_the_persistent_kernels_would_take(oracle, monkeypatch):
+    """Two launches of the fp32 persistent kernel reach up to 8192 frames at N 1024 -- above the size from which a call is submitted as whole-batch
+    launches (2 x 3072 frames): a submitted job never takes the persistent path (it wants a verifying wait), a synchronous call of that size does."""
+    monkeypatch.delenv("GOMEL_PRECISION", raising=False)
+    fields = dict(S, GriffinLimIterations=6)
+    K, U, F = 80, 35, 200
+    eng = mel_obj(fields).engine()
+    eng.set_precision(32)
+    mels, seeds = inputs(U, F, K, first=7)
+    _, tm = run_batch(eng, mels, seeds)
+    assert tm["fast_path"] == 2 and tm["frames"] == U * F          # the resident batch: persistent, two launches
+    job = eng.submit_f32([a.astype(np.float32) for a in mels], None, seeds)
+    got = [np.array(v) for v in job.wait()]
+    eng.set_call_mode(1)
+    want = eng.from_mel_batch_f32([a.astype(np.float32) for a in mels], None, seeds)
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    ref = eng.from_mel_batch(mels, None, seeds)
+    assert max(rms(g - r) for g, r in zip(got, ref)) < 1e-4
+    eng.close()
+
+
 @pytest.mark.parametrize("N,hop,F,I", [(1024, 256, 9, 3), (4096, 1280, 40, 6), (2048, 300, 25, 4)])
 def test_exported_istft_in_the_default_mode(oracle, N, hop, F, I, monkeypatch):
     """ISTFT(s, spectrogram, numIterations) (mel/mel.go:76-139) on a handle nobody touched: from a list (no write-back: the default

@@ -1980,7 +1980,9 @@ static int from_mel_batch_chunked(gomel_handle* h, size_t n_utt, const void* con
     }
     auto cstream = [&](int c) { return (n_cs == 2 && h->stream2 && (c & 1)) ? h->stream2 : h->stream; };
     auto create = [&](int c) {
-        int r = batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], io32 ? BF_IO32 : 0, -1, &chunks[c], h->up_stream);
+        // (a call cut into several chunks keeps them off the persistent path: its verifying wait would stall the copy / compute pipeline --
+        // two-launch persistent batches reach chunk sizes at the small frame lengths; a call that is ONE chunk takes it as before)
+        int r = batch_create_common(h, bounds[c + 1] - bounds[c], n_pairs + bounds[c], (io32 ? BF_IO32 : 0) | (n_chunks > 1 ? BF_NOPERSIST : 0), -1, &chunks[c], h->up_stream);
         if (!r) chunks[c]->rs = cstream(c);
         return r;
     };

@@ -23,7 +23,8 @@ GEOMS = {"T": (dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096), 44
          "D": (dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), 22050),
          "X": (dict(NumMels=80, MelFmax=8000.0, Window=128, Resolut=1024), 22050),        # eight-fold overlap at another frame length
          "W": (dict(NumMels=80, MelFmax=8000.0, Window=64, Resolut=1024), 22050),         # sixteen-fold
-         "Y": (dict(NumMels=160, MelFmax=8000.0, Window=512, Resolut=2048), 22050)}       # four-fold at N 2048
+         "Y": (dict(NumMels=160, MelFmax=8000.0, Window=512, Resolut=2048), 22050),       # four-fold at N 2048
+         "Z": (dict(NumMels=160, MelFmax=8000.0, Window=400, Resolut=2048), 22050)}       # 5.1-fold: just under the second table's rule
 DEFAULT_GRID = {2: [0, 1], 5: [0, 2, 3], 10: [0, 2, 4, 6], 20: [0, 4, 8, 12, 16], 30: [0, 5, 10, 15, 20], 40: [0, 10, 15, 20, 25, 30],
                 60: [0, 10, 20, 24, 26, 28, 30, 35, 40, 45], 100: [0, 20, 40, 50, 60, 70, 80]}
 U, F = 256, 400

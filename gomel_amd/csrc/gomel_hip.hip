@@ -245,7 +245,7 @@ static int validate_config(const gomel_config* c) {
 // (The first table's entry for 20 iterations rose from the calibration's 10 to 14: 65 536 held-out TTS-geometry spectrograms left 4 / 17 at 10, 1 / 3 at 14.)
 struct AutoPoint { int iters, k; };
 static const AutoPoint kAutoSchedule[] = {{2, 2}, {5, 5}, {10, 6}, {20, 14}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};        // profiles/r04/calibration/TABLE.txt; 20: 10 -> 14 by val3_S_random_65536_otherI.txt
-static const AutoPoint kAutoScheduleDense[] = {{2, 2}, {5, 5}, {10, 6}, {20, 16}, {30, 25}, {40, 32}, {60, 50}, {100, 90}};   // profiles/r04/validation/val3_D_random_*
+static const AutoPoint kAutoScheduleDense[] = {{2, 2}, {5, 5}, {10, 6}, {20, 16}, {30, 27}, {40, 32}, {60, 50}, {100, 90}};   // profiles/r04/validation/val3_D_random_*
 static bool auto_dense(const gomel_config& c) { return c.window > 0 && (int64_t)c.window * 6 <= (int64_t)c.resolut; }
 static int auto_fp64_iterations(const gomel_config& c, int I) {
     const AutoPoint* tab = auto_dense(c) ? kAutoScheduleDense : kAutoSchedule;

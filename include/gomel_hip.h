@@ -249,7 +249,7 @@ int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations);
  * in between: {2:2, 5:5, 10:6, 20:14, 30:25, 40:30, 60:35, 100:80} (up to five iterations -- the reference's shipped 2 among them -- fp64 throughout, 20:
  * raised from the calibration's 10: larger held-out runs, profiles/r04/validation/val3_*).  Geometries whose frames overlap six-fold or more (Window <= Resolut / 6;
  * NewMel's defaults overlap eight-fold) carry a heavier tail -- 6 of 131 072 held-out random spectrograms beyond 1e-4 at 35 of 60, none
- * beyond 3e-5 at 50 (profiles/r04/validation/val3_*) -- and take {2:2, 5:5, 10:6, 20:16, 30:25, 40:32, 60:50, 100:90}.
+ * beyond 3e-5 at 50 (profiles/r04/validation/val3_*) -- and take {2:2, 5:5, 10:6, 20:16, 30:27, 40:32, 60:50, 100:90}.
  * Generic frame lengths: = iterations (their kernels are fp64).  Negative iterations / NULL cfg: 0. */
 int32_t gomel_auto_fp64_iterations(const gomel_config* cfg, int32_t iterations);
 /* What a call of `iterations` iterations (negative: the handle's GriffinLimIterations) on this handle will do under its current

@@ -84,7 +84,7 @@ def test_automatic_precision_schedule_table(L):
     k = lambda i: L.gomel_auto_fp64_iterations(ctypes.byref(c), i)
     # NewMel's defaults (Resolut 2048 / hop 256) overlap eight-fold: geometries with hop <= Resolut / 6 take the second table (the larger
     # held-out runs of profiles/r04/validation/val3_*: 6 of 131 072 beyond 1e-4 at 35 of 60, none beyond 3e-5 at 50)
-    dense = {2: 2, 5: 5, 10: 6, 20: 16, 30: 25, 40: 32, 60: 50, 100: 90}
+    dense = {2: 2, 5: 5, 10: 6, 20: 16, 30: 27, 40: 32, 60: 50, 100: 90}
     assert [k(i) for i in sorted(dense)] == [dense[i] for i in sorted(dense)] and k(300) == 290 and k(50) == 41
     c.window = 342                                                        # just above Resolut / 6: the first table
     assert k(60) == 35

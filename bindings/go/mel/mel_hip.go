@@ -59,8 +59,14 @@ func statusErr(rc C.int) error {
 	if rc == C.GOMEL_OK {
 		return nil
 	}
+	if rc == C.GOMEL_ERR_BUSY {
+		return ErrBusy
+	}
 	return errors.New("gomel_hip: " + C.GoString(C.gomel_strerror(rc)))
 }
+
+// ErrBusy: gomel_destroy was called on a handle with submitted jobs that have not been waited for (GOMEL_ERR_BUSY); the handle stays valid.
+var ErrBusy = errors.New("gomel_hip: handle busy: submitted jobs have not been waited for")
 
 // ---- handle cache -------------------------------------------------------------------------------------------------------
 

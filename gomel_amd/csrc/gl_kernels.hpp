@@ -452,6 +452,15 @@ template <bool WIDE> struct StreamFlagSync {
 };
 
 constexpr int kFusedThreads = 256;
+#ifndef GL_PAIRED
+#define GL_PAIRED 0   // the fused kernels' forward / inverse FFT as a pair: no synchronisation between pass 3's reads and the inverse's first writes (gl_fft.hpp)
+#endif
+#ifndef GL_D_WN_EARLY
+#define GL_D_WN_EARLY 0
+#endif
+#ifndef GL_D_MAGS_EARLY
+#define GL_D_MAGS_EARLY 0
+#endif
 #ifndef GL_WIN_B128
 #define GL_WIN_B128 0
 #endif
@@ -1139,7 +1148,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         };
         if constexpr (!fused_late_rows(N)) issue_rows();
         st.mark(15);
-        fft_forward<G>(v, my, t, tw, sync, st);
+        fft_forward<G, GL_PAIRED>(v, my, t, tw, sync, st);
         {
             MagRegs mr;
             finish_mags(mr, mraw, t == 0);
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         }
         st.mark(7);
         if constexpr (fused_late_rows(N)) issue_rows();
-        fft_inverse<G>(v, my, t, tw, sync, st);
+        fft_inverse<G, GL_PAIRED>(v, my, t, tw, sync, st);
         // The next frame's rows: unpacked BEFORE this frame's stores are issued.  vmcnt counts loads and stores in issue order,
         // so a wait placed behind the (conditional) stores below would have to drain them too -- a full store round trip at the
         // end of every frame; here only loads issued a frame's worth of cycles ago are pending.
@@ -1478,6 +1487,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
     constexpr bool WN_LDS = GL_D_WN_LDS && N >= GL_D_WN_LDS_MINN;
+    constexpr bool WN_EARLY = GL_D_WN_EARLY && WN_LDS;
     v2d* wn_l = win_l + G::C;                                  // [8][T] (WN_LDS only)
     int* g_sh = reinterpret_cast<int*>(wn_l + (WN_LDS ? 8 * T : 0));
     unsigned* cnt_sh = reinterpret_cast<unsigned*>(g_sh + STREAMS);   // [STREAMS][2]: one event counter per wave of a two-wave stream (N 4096)
@@ -1565,12 +1575,21 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
 #else
     NoStamps st;
 #endif
+#if GL_D_MAGS_EARLY
+    MagRawD mnext;
+    load_mag_rows_d<G>(mnext, t, mag_p);
+    mnext.nq = nyq_p[0];
+#endif
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
+#if GL_D_MAGS_EARLY
+        MagRawD mraw = mnext;                                                 // requested at the start of the previous frame's inverse FFT
+#else
         MagRawD mraw;                                                         // issued now, finished after the forward FFT
         load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
         mraw.nq = nyq_p[gg];
+#endif
         st.mark(16);
         // (k_gl_fused's single window read per frame was tried here too: 64 more live registers around the back edge, 3 % MORE
         // vector instructions through the AGPR traffic they cause -- the window is read twice)
@@ -1596,22 +1615,30 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
         }
         st.mark(15);   // (window reads + multiply, slide, next rows' loads issued)
         if constexpr (W1CARRY) {
-            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr};
-            fft_forward<G>(v, my, t, twf, sync, st);
+            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr, WN_EARLY ? wn_l : nullptr, WN_EARLY ? wn : nullptr};
+            fft_forward<G, GL_PAIRED>(v, my, t, twf, sync, st);
         } else {
-            fft_forward<G>(v, my, t, tw, sync, st);
+            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, nullptr, 0, nullptr, WN_EARLY ? wn_l : nullptr, WN_EARLY ? wn : nullptr};
+            fft_forward<G, GL_PAIRED>(v, my, t, twf, sync, st);
         }
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
-            if constexpr (WN_LDS) {
+            if constexpr (WN_LDS && !WN_EARLY) {
 #pragma unroll
                 for (int s8 = 0; s8 < 8; s8++) wn[s8] = wn_l[s8 * T + t];
             }
             spectral_apply<G>(v, t, mr, wn);
         }
+#if GL_D_MAGS_EARLY
+        {   // the next frame's magnitude row and Nyquist scalar: the inverse FFT covers their latency, the frame's head carries five loads less
+            const int gn = g + 1 < d.G ? g + 1 : d.G - 1;
+            load_mag_rows_d<G>(mnext, t, mag_p + (int64_t)gn * G::C);
+            mnext.nq = nyq_p[gn];
+        }
+#endif
         st.mark(7);
-        fft_inverse<G>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
+        fft_inverse<G, GL_PAIRED>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] = xl[jj];
         if (any_next) {

@@ -224,31 +224,21 @@ static int validate_config(const gomel_config* c) {
     return GOMEL_OK;
 }
 
-// The automatic precision schedule: how many of a call's I Griffin-Lim iterations run in fp64 before the fp32 kernels take over.
-// CALIBRATED on the GPU (scripts/calibrate_schedule.py, profiles/r04/calibration/): for every I below and the three geometries
-// towav (N 4096 / hop 1280), TTS (1024 / 256) and NewMel's defaults (2048 / 256), 4096 iid-random and 4096 signal-derived
-// utterances of 400 frames each; the entry is the smallest k tried for which NO utterance of any of the six sets ended more than
-// 3e-5 RMS from fp64 throughout (a 3x margin under the 1e-4 bar of SURVEY 8(b): the error distribution is heavy-tailed, DESIGN.md
-// section 2).  What the data show (24 576 utterances per schedule): the iteration is most unstable in its FIRST iterations, from the
-// random initial signal (mel/mel.go:80-83) -- fp32 throughout leaves 1.1 % of 60-iteration utterances beyond 1e-4, ten fp64 iterations
-// first 0.1 %, 35 none of the 24 576 -- but the tail never closes: single utterances amplify the rounding of the LAST fifteen iterations
-// a thousandfold (one of 24 576 beyond 1e-4 at k = 45 of 60), so a schedule bounds the RATE of such utterances, about 1 in 10^4 to 10^5
-// at these entries; only fp64 throughout excludes them.  Even two fp32 iterations leave 2 of 24 576 beyond 3e-5, hence k(2) = 1.
-// Between calibrated points k is interpolated upwards; beyond the last one the number of trailing fp32 iterations is held (20; 10 in the second table).
-// Geometries whose frames overlap six-fold or more (hop <= Resolut / 6; NewMel's defaults overlap eight-fold) have the heavier tail: a
-// larger held-out run (131 072 random spectrograms of the NewMel geometry at 60 iterations, profiles/r04/validation/val3_*) found 6 beyond
-// 1e-4 and 27 beyond 3e-5 at k = 35, 0 / 2 at 45, 0 / 0 at 50; at 20 iterations 1 / 9 of 65 536 at k = 10, 0 / 0 at 16; at 100 1 / 4 at 80,
-// 0 / 1 at 90 -- while 225 280 utterances of the towav geometry show none beyond 1e-4 at the first table's 35.  They take the second table.
-// Up to five iterations everything runs in fp64 (the reference's shipped GriffinLimIterations = 2, mel/mel.go:39, among them): a single trailing fp32
-// iteration already leaves 1 of 65 536 held-out spectrograms 3-5e-4 away at two of the three geometries (a clamp flip of a near-zero bin,
-// val3_I2_I5_65536.txt), and calls that short cost next to nothing.
-// (The first table's entry for 20 iterations rose from the calibration's 10 to 14: 65 536 held-out TTS-geometry spectrograms left 4 / 17 at 10, 1 / 3 at 14.)
+// The automatic precision schedule: how many of a call's I Griffin-Lim iterations run in fp64 before the fp32 kernels take over
+// (mel/mel.go:76-139 is float64 throughout; the schedule keeps the default call within the 1e-4 RMS bar of SURVEY 8(b) at a calibrated
+// RATE -- fp64 throughout, gomel_set_precision(h, 64), is the guarantee).  Two calibrated tables (scripts/calibrate_schedule.py; how they
+// were made, and every held-out tally, is DESIGN.md section 2 / LABBOOK.md): kAutoSchedule for frames that overlap up to four-fold
+// (towav: N 4096 / hop 1280; TTS: 1024 / 256), kAutoScheduleDense from six-fold on (NewMel's defaults, mel/mel.go:30-41: 2048 / 256, eight-fold).
+// The rule is MONOTONE in the overlap Resolut / Window: between four- and six-fold k is interpolated linearly between the two tables'
+// values, rounded up (N 2048 / hop 400, 5.12-fold: 44 of 60).  Between calibrated iteration counts k is interpolated upwards; beyond the
+// last one the number of trailing fp32 iterations is held; up to five iterations run in fp64 throughout (the reference's shipped
+// GriffinLimIterations = 2, mel/mel.go:39, among them).
+// FROZEN in round 5: no table edit without a new failing full-size test (tests/test_gpu_round5.py holds the default call to < 1e-4 on
+// 256 x 400 frames at the NewMel-default geometry and on the interpolated stretch).
 struct AutoPoint { int iters, k; };
-static const AutoPoint kAutoSchedule[] = {{2, 2}, {5, 5}, {10, 6}, {20, 14}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};        // profiles/r04/calibration/TABLE.txt; 20: 10 -> 14 by val3_S_random_65536_otherI.txt
-static const AutoPoint kAutoScheduleDense[] = {{2, 2}, {5, 5}, {10, 6}, {20, 16}, {30, 27}, {40, 32}, {60, 50}, {100, 90}};   // profiles/r04/validation/val3_D_random_*
-static bool auto_dense(const gomel_config& c) { return c.window > 0 && (int64_t)c.window * 6 <= (int64_t)c.resolut; }
-static int auto_fp64_iterations(const gomel_config& c, int I) {
-    const AutoPoint* tab = auto_dense(c) ? kAutoScheduleDense : kAutoSchedule;
+static const AutoPoint kAutoSchedule[] = {{2, 2}, {5, 5}, {10, 6}, {20, 14}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};        // overlap <= 4
+static const AutoPoint kAutoScheduleDense[] = {{2, 2}, {5, 5}, {10, 6}, {20, 16}, {30, 27}, {40, 32}, {60, 50}, {100, 90}};   // overlap >= 6
+static int auto_table_k(const AutoPoint* tab, int I) {
     constexpr int n = (int)(sizeof kAutoSchedule / sizeof kAutoSchedule[0]);
     static_assert(sizeof kAutoSchedule == sizeof kAutoScheduleDense, "the two tables have the same calibrated iteration counts");
     if (I <= tab[0].iters) return std::min(I, tab[0].k);
@@ -259,6 +249,14 @@ static int auto_fp64_iterations(const gomel_config& c, int I) {
             return std::min(I, std::max(k, a.k));
         }
     return I - (tab[n - 1].iters - tab[n - 1].k);
+}
+static int auto_fp64_iterations(const gomel_config& c, int I) {
+    const int k_lo = auto_table_k(kAutoSchedule, I), k_hi = std::max(k_lo, auto_table_k(kAutoScheduleDense, I));
+    const int64_t N = c.resolut, hop = c.window;
+    if (hop <= 0 || N <= 4 * hop) return k_lo;                  // overlap <= 4 (hops >= Resolut included)
+    if (N >= 6 * hop) return k_hi;                              // overlap >= 6
+    const int64_t num = (int64_t)(k_hi - k_lo) * (N - 4 * hop), den = 2 * hop;   // (k_hi - k_lo) * (overlap - 4) / 2
+    return std::min(I, k_lo + (int)((num + den - 1) / den));
 }
 // fp64 iterations of a call of I iterations on this handle: 0 = fp32 throughout, >= I = fp64 throughout.  Caller holds h->mu.
 static int resolve_fp64_iterations(const gomel_handle* h, int I) {
@@ -1404,6 +1402,7 @@ const char* gomel_strerror(int s) {
         case GOMEL_ERR_BAD_TABLES: return "table blob does not match the configuration";
         case GOMEL_ERR_TOO_SHORT: return "padded input shorter than one frame";
         case GOMEL_ERR_NO_MEMORY: return "host allocation failed";
+        case GOMEL_ERR_BUSY: return "handle busy: submitted jobs have not been waited for";
         default: return "unknown status";
     }
 }
@@ -1522,7 +1521,7 @@ int gomel_get_precision(const gomel_handle* h, int32_t iterations, int32_t* fp64
 
 int gomel_destroy(gomel_handle* h) {
     if (!h) return GOMEL_OK;
-    if (h->jobs_outstanding.load() != 0) return GOMEL_ERR_NULL;   // call out of order: a submitted job has not been waited for (its buffers live in this handle)
+    if (h->jobs_outstanding.load() != 0) return GOMEL_ERR_BUSY;   // a submitted job has not been waited for (its buffers live in this handle)
     {
     DeviceGuard dg(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }

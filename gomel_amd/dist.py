@@ -108,20 +108,30 @@ def gpu_bus_ids(smi="rocm-smi", timeout=30):
     return ids
 
 
-def visible_index(local_rank, env=None):
-    """The physical GPU index behind this rank's device ordinal: through ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when they hold
-    plain indices (the launcher's usual form), else the ordinal itself."""
+def visible_index_why(local_rank, env=None):
+    """(index, why): the physical GPU index behind this rank's device ordinal, or (None, reason) when it cannot be told.
+    HIP_VISIBLE_DEVICES and CUDA_VISIBLE_DEVICES are ALIASES to the HIP runtime (one filter, not two: the first of them that is set
+    wins, HIP_ before CUDA_); ROCR_VISIBLE_DEVICES filters one layer below (the HIP ordinals index ROCR's list).  Only plain index
+    lists -- the launcher's usual form -- are mapped; UUIDs or a list shorter than the ordinal are not guessed at."""
     env = os.environ if env is None else env
     idx = local_rank
-    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):   # applied innermost first
-        v = env.get(var, "").strip()
+    hip_level = next((var for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if env.get(var, "").strip()), None)
+    for var in (hip_level, "ROCR_VISIBLE_DEVICES"):       # applied innermost first
+        v = env.get(var, "").strip() if var else ""
         if not v:
             continue
         parts = [p.strip() for p in v.split(",")]
-        if not all(p.isdigit() for p in parts) or idx >= len(parts):
-            return None                                    # UUIDs or a short list: do not guess
+        if not all(p.isdigit() for p in parts):
+            return None, "%s=%r is not a list of indices" % (var, v)
+        if idx >= len(parts):
+            return None, "%s=%r lists %d device(s), ordinal %d asked for" % (var, v, len(parts), idx)
         idx = int(parts[idx])
-    return idx
+    return idx, None
+
+
+def visible_index(local_rank, env=None):
+    """The physical GPU index behind this rank's device ordinal (None when it cannot be told: visible_index_why says why)."""
+    return visible_index_why(local_rank, env)[0]
 
 
 def bind_to_gpu_numa_node(local_rank, sysfs="/sys", bus_ids=None, env=None, setaffinity=None, getaffinity=None):
@@ -133,9 +143,9 @@ def bind_to_gpu_numa_node(local_rank, sysfs="/sys", bus_ids=None, env=None, seta
     information is not an error).  sysfs / bus_ids / env / the affinity calls are injectable for the CPU tests."""
     setaffinity = setaffinity or (lambda cpus: os.sched_setaffinity(0, cpus))
     getaffinity = getaffinity or (lambda: os.sched_getaffinity(0))
-    idx = visible_index(local_rank, env)
+    idx, why = visible_index_why(local_rank, env)
     if idx is None:
-        return {"bound": False, "why": "device visibility is not a list of indices"}
+        return {"bound": False, "why": "device visibility: " + why}
     ids = gpu_bus_ids() if bus_ids is None else list(bus_ids)
     if idx >= len(ids):
         return {"bound": False, "why": "no PCI bus id for GPU %d (%d listed)" % (idx, len(ids))}

@@ -44,7 +44,8 @@ typedef enum gomel_status {
     GOMEL_ERR_NO_DEVICE = 9,
     GOMEL_ERR_BAD_TABLES = 10,    /* injected table blob does not match the configuration                         */
     GOMEL_ERR_TOO_SHORT = 11,     /* ToMel: padded input shorter than one frame                                   */
-    GOMEL_ERR_NO_MEMORY = 12      /* host allocation failed (C++ exceptions never cross the boundary)             */
+    GOMEL_ERR_NO_MEMORY = 12,     /* host allocation failed (C++ exceptions never cross the boundary)             */
+    GOMEL_ERR_BUSY = 13           /* gomel_destroy with submitted jobs not yet waited for: the handle stays valid  */
 } gomel_status;
 
 /* Mirrors `type Mel` (mel/mel.go:10-27).  YReverse, VolumeBoost and SampleRate only matter to the PNG/WAV
@@ -106,7 +107,7 @@ int gomel_set_window(gomel_handle* h, const double* window, size_t n);
 int gomel_get_window(const gomel_handle* h, double* window, size_t cap);
 
 /* Destroy every gomel_batch created from the handle first, and wait for every submitted job: with jobs outstanding the call is
- * refused (GOMEL_ERR_NULL, "call out of order") and the handle stays valid. */
+ * refused (GOMEL_ERR_BUSY) and the handle stays valid. */
 int gomel_destroy(gomel_handle* h);
 
 /* len(reconstructedSignal), mel/mel.go:80.  0 on bad arguments. */
@@ -223,10 +224,9 @@ int gomel_batch_destroy(gomel_batch* b);
  * the handle leaves that path alone for its next 64 batches (doubling with every further timeout, up to 4096). */
 int gomel_set_path(gomel_handle* h, int mode);
 /* Arithmetic of the Griffin-Lim iterations (mel/mel.go:85-136 is float64 / complex128 throughout) for batches created afterwards:
- *   0  (default) AUTOMATIC: the calibrated precision schedule gomel_auto_fp64_iterations(cfg, I) -- the call a caller gets without
- *      a knob ends within 1e-4 RMS of the reference's float64 arithmetic on every utterance of the calibration sets (below) and on
- *      all but 1 of 536 576 held-out random spectrograms at 60 iterations (towav geometry 0 of 225 280, TTS geometry 1 of 180 224, NewMel-default geometry 0 of 131 072 with its second table below; 4 of 540 672 at eleven other iteration counts with the first table): a rate below 1e-5, not a guarantee (Griffin-Lim amplifies rounding without bound on a
- *      few inputs);
+ *   0  (default) AUTOMATIC: the calibrated precision schedule gomel_auto_fp64_iterations(cfg, I).  Contract: calibrated, not
+ *      guaranteed -- the call ends within 1e-4 RMS of the reference's float64 arithmetic except on about one utterance in 10^5
+ *      (Griffin-Lim amplifies rounding without bound on a few inputs; measurements: DESIGN.md section 2);
  *   32 fp32 kernels for every iteration: the opt-in FAST mode (1.7x the default's rate at 60 iterations).  Typically 1e-6 from the
  *      fp64 arithmetic, but ~1 % of 60-iteration utterances end beyond 1e-4;
  *   64 fp64 kernels for every iteration (~1e-13 from the fp64 restatement of the reference): the mode that is guaranteed on every input. */
@@ -243,13 +243,12 @@ int gomel_set_precision(gomel_handle* h, int bits);
  * gomel_istft_spec run fp64 throughout whenever the schedule asks for any fp64 iteration at all. */
 #define GOMEL_SCHEDULE_AUTO (-2147483647 - 1)
 int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations);
-/* The automatic schedule: of a call of `iterations` Griffin-Lim iterations, how many run in fp64 first.  Host logic only.  Calibrated on the GPU for iterations in
- * {2, 5, 10, 20, 30, 40, 60, 100} on the towav, TTS and NewMel-default geometries, 4096 random and 4096 signal-derived utterances
- * each: the smallest k that left no utterance beyond 3e-5 RMS of fp64 throughout (profiles/r04/calibration/); interpolated upwards
- * in between: {2:2, 5:5, 10:6, 20:14, 30:25, 40:30, 60:35, 100:80} (up to five iterations -- the reference's shipped 2 among them -- fp64 throughout, 20:
- * raised from the calibration's 10: larger held-out runs, profiles/r04/validation/val3_*).  Geometries whose frames overlap six-fold or more (Window <= Resolut / 6;
- * NewMel's defaults overlap eight-fold) carry a heavier tail -- 6 of 131 072 held-out random spectrograms beyond 1e-4 at 35 of 60, none
- * beyond 3e-5 at 50 (profiles/r04/validation/val3_*) -- and take {2:2, 5:5, 10:6, 20:16, 30:27, 40:32, 60:50, 100:90}.
+/* The automatic schedule: of a call of `iterations` Griffin-Lim iterations, how many run in fp64 first.  Host logic only.
+ * Two calibrated tables over the iteration count (interpolated upwards between calibrated counts; the trailing fp32 iterations are
+ * held beyond the last one; up to five iterations -- the reference's shipped 2, mel/mel.go:39, among them -- run in fp64 throughout):
+ * one for frames that overlap up to four-fold (Resolut <= 4 * Window), one from six-fold on (Resolut >= 6 * Window, NewMel's
+ * defaults, mel/mel.go:30-41); in between the result is interpolated linearly in the overlap Resolut / Window and rounded up, so the
+ * rule is monotone in the iteration count and in the overlap.  The tables and the data behind them: gomel_hip.hip, DESIGN.md section 2.
  * Generic frame lengths: = iterations (their kernels are fp64).  Negative iterations / NULL cfg: 0. */
 int32_t gomel_auto_fp64_iterations(const gomel_config* cfg, int32_t iterations);
 /* What a call of `iterations` iterations (negative: the handle's GriffinLimIterations) on this handle will do under its current

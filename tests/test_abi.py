@@ -82,14 +82,30 @@ def test_automatic_precision_schedule_table(L):
     c = GomelConfig()
     L.gomel_default_config(ctypes.byref(c))
     k = lambda i: L.gomel_auto_fp64_iterations(ctypes.byref(c), i)
-    # NewMel's defaults (Resolut 2048 / hop 256) overlap eight-fold: geometries with hop <= Resolut / 6 take the second table (the larger
-    # held-out runs of profiles/r04/validation/val3_*: 6 of 131 072 beyond 1e-4 at 35 of 60, none beyond 3e-5 at 50)
+    # NewMel's defaults (Resolut 2048 / hop 256, mel/mel.go:30-41) overlap eight-fold: from six-fold on the second table applies
     dense = {2: 2, 5: 5, 10: 6, 20: 16, 30: 27, 40: 32, 60: 50, 100: 90}
     assert [k(i) for i in sorted(dense)] == [dense[i] for i in sorted(dense)] and k(300) == 290 and k(50) == 41
-    c.window = 342                                                        # just above Resolut / 6: the first table
-    assert k(60) == 35
-    c.window = 341
-    assert k(60) == 50
+    # the rule over the overlap Resolut / Window (round 5): first table up to four-fold, second from six-fold, linear in between,
+    # rounded up -- monotone in the overlap at every iteration count
+    c.window = 512; assert k(60) == 35                                    # four-fold: the first table
+    c.window = 513; assert k(60) == 35                                    # less overlap
+    c.window = 2048; assert k(60) == 35 and k(20) == 14                   # hop = Resolut
+    c.window = 3000; assert k(60) == 35                                   # hop > Resolut
+    c.window = 511; assert k(60) == 36                                    # just over four-fold: rounded up
+    c.window = 400; assert k(60) == 44 and k(20) == 16 and k(100) == 86   # 5.12-fold: 35 + ceil(15 * 0.56); 0 of 65 536 beyond 3e-5 at 42 (LABBOOK.md)
+    c.window = 342; assert k(60) == 50                                    # 5.99-fold: ceil lands on the second table
+    c.window = 341; assert k(60) == 50                                    # six-fold and beyond: the second table
+    c.window = 64; assert k(60) == 50
+    for iters in (2, 5, 10, 17, 20, 30, 45, 60, 100, 250):
+        ks = []
+        for hop in range(2048, 100, -1):
+            c.window = hop
+            ks.append(k(iters))
+        assert all(b >= a for a, b in zip(ks, ks[1:])), iters            # more overlap never means fewer fp64 iterations
+        assert all(0 <= v <= iters for v in ks)
+    c.window = 400
+    ks = [k(i) for i in range(0, 400)]
+    assert all(0 <= v <= i for i, v in enumerate(ks)) and all(b >= a for a, b in zip(ks, ks[1:]))   # ... and monotone in the iteration count there too
     c.resolut, c.window = 4096, 1280                                      # the towav geometry: the first table
     table = {2: 2, 5: 5, 10: 6, 20: 14, 30: 25, 40: 30, 60: 35, 100: 80}
     txt = open(os.path.join(ROOT, "profiles", "r04", "calibration", "TABLE.txt")).read()
@@ -142,7 +158,9 @@ def test_config_validation_statuses(L):
         assert L.gomel_create(ctypes.byref(c), ctypes.byref(h)) == status, field
     assert L.gomel_create(None, ctypes.byref(h)) == 7
     assert b"NumMels" in L.gomel_strerror(3) and L.gomel_strerror(0) == b"ok" and L.gomel_strerror(999) == b"unknown status"
-    assert all(L.gomel_strerror(s) != b"unknown status" for s in range(13))      # every code of the header has a message
+    assert all(L.gomel_strerror(s) != b"unknown status" for s in range(14))      # every code of the header has a message
+    hdr = open(os.path.join(ROOT, "include", "gomel_hip.h")).read()
+    assert "GOMEL_ERR_BUSY = 13" in hdr and b"busy" in L.gomel_strerror(13)       # gomel_destroy with jobs outstanding (round 5; was GOMEL_ERR_NULL)
 
 
 def test_product_never_imports_the_oracle():

@@ -104,12 +104,20 @@ def test_rank_binds_to_the_cpus_of_its_gpus_numa_node(tmp_path):
     assert r["bound"] and r["bdf"] == "0000:85:00.0"
     r = gd.bind_to_gpu_numa_node(0, env={"HIP_VISIBLE_DEVICES": "1", "ROCR_VISIBLE_DEVICES": "2,0"}, **kw)   # HIP index 1 of ROCR's list -> GPU 0
     assert r["bound"] and r["bdf"] == "0000:05:00.0" and got["cpus"] == {0, 1, 2, 3, 16, 17, 18, 19}
+    # HIP_ and CUDA_VISIBLE_DEVICES are aliases to the HIP runtime: ONE filter (the first set wins), never composed -- both set to
+    # the same permutation still means "ordinal 0 is physical GPU 1", not "GPU 0"
+    r = gd.bind_to_gpu_numa_node(0, env={"HIP_VISIBLE_DEVICES": "1,0", "CUDA_VISIBLE_DEVICES": "1,0"}, **kw)
+    assert r["bound"] and r["bdf"] == "0000:85:00.0"
+    r = gd.bind_to_gpu_numa_node(1, env={"CUDA_VISIBLE_DEVICES": "1,0"}, **kw)            # CUDA_ alone is honoured
+    assert r["bound"] and r["bdf"] == "0000:05:00.0"
+    assert gd.visible_index(0, {"HIP_VISIBLE_DEVICES": "2", "CUDA_VISIBLE_DEVICES": "0,1"}) == 2     # HIP_ before CUDA_
+    assert gd.visible_index_why(3, {"HIP_VISIBLE_DEVICES": "0,1"}) == (None, "HIP_VISIBLE_DEVICES='0,1' lists 2 device(s), ordinal 3 asked for")
     got.clear()
     allowed = {0, 1, 4}
     kw["getaffinity"] = lambda: allowed
     r = gd.bind_to_gpu_numa_node(1, env={}, **kw)                                        # cgroup / taskset mask respected
     assert r["bound"] and got["cpus"] == {4}
-    for rank, env, why in ((2, {}, "numa_node = -1"), (5, {}, "no PCI bus id"), (0, {"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}, "not a list of indices")):
+    for rank, env, why in ((2, {}, "numa_node = -1"), (5, {}, "no PCI bus id"), (0, {"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}, "ROCR_VISIBLE_DEVICES='GPU-abcdef' is not a list of indices")):
         got.clear()
         r = gd.bind_to_gpu_numa_node(rank, env=env, **kw)
         assert not r["bound"] and why in r["why"] and not got

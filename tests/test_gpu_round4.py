@@ -178,9 +178,9 @@ def test_submitted_jobs_equal_the_whole_batch_bit_for_bit(oracle, mode, monkeypa
     assert js.done()
     want = eng.from_mel_batch(small_m, None, small_s)
     assert all(np.array_equal(a, b) for a, b in zip(js.wait(), want))
-    # a handle with a job outstanding refuses to be destroyed (status 7, "call out of order") and stays usable
+    # a handle with a job outstanding refuses to be destroyed (GOMEL_ERR_BUSY = 13) and stays usable
     jd = eng.submit_bound(bound[0], sets[0][1])
-    assert gomel_amd._lib.lib().gomel_destroy(eng._h) == 7
+    assert gomel_amd._lib.lib().gomel_destroy(eng._h) == 13 and b"busy" in gomel_amd._lib.lib().gomel_strerror(13)
     assert all(np.array_equal(a, b) for a, b in zip(jd.wait(), refs[0]))
     # errors surface at submit, nothing is left in flight
     with pytest.raises(gomel_amd.GomelError):

@@ -12,20 +12,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gl_types.hpp"
 #include "gl_fft.hpp"
 #include "gl_any.hpp"
 #include "gl_big.hpp"
 
 using namespace glfft;
+static_assert(glbig::kMaxN == kBigMaxN, "gl_types.hpp and gl_big.hpp agree on the longest frame");
 
 // =============================================================================================== device tables
-struct BinRow {  // one linear bin of undomel (or one mel band of domel): data-independent index math, built in fp64 on host
-    int32_t lo, hi;
-    int32_t mode;  // 0 copy band lo; 1 two-tap lo,hi with modlo; 2 sum lo..hi-1 divided by div
-    int32_t pad_;
-    double modlo, div;
-};
-
 struct DevTables {
     glany::AnyTables any;  // generic-length path (gl_any.hpp); any.M == 0 when the register cores cover Resolut
     glbig::BigTables big;  // frame lengths above 8192 (gl_big.hpp): big.Mc != 0; `any` then describes the 8192-point LDS transform
@@ -50,15 +45,6 @@ struct DevTables {
         case 512:  { constexpr int NN = 512;  __VA_ARGS__; } break; \
         default:   { constexpr int NN = 256;  __VA_ARGS__; } break; \
     }
-static inline bool gomel_supported_n(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; }
-// what gl_any.hpp covers besides: every other length (odd ones too) up to 8192 (radix-2; Bluestein, above 4096 in its split form);
-// gl_big.hpp: 8193 ... 65536 (Bluestein through HBM)
-static inline bool gomel_generic_n(int n) {
-    if (n < 4 || gomel_supported_n(n)) return false;
-    return n <= glbig::kMaxN;
-}
-static inline bool gomel_big_n(int n) { return n > 8192 && n <= glbig::kMaxN; }
-
 GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
     if (r.mode == 0) return e[r.lo];
     if (r.mode == 1) return e[r.lo] * (1 - r.modlo) + e[r.hi] * r.modlo;
@@ -76,7 +62,6 @@ GL_DEV double apply_row(const BinRow r, const double* __restrict__ e) {
 // Channel 1 feeds bin N/2-1 only, so its exp() is taken for the one or two bands that row reads, not for all K (the fp64
 // exp() was what bounded this kernel).  Reads K*16 B, writes (N/2+1)*4 B per frame.
 constexpr int kMagFramesPerBlock = 8;        // fewer when NumMels is large: the exp() rows of a block must fit its LDS (launch_mel_to_mag)
-constexpr int kMaxMels = 16384;              // NumMels beyond this cannot keep one frame's exp() row in the 160 KiB LDS
 
 template <class InT> GL_DEV double apply_row_ch1(const BinRow r, const InT* __restrict__ m) {   // apply_row on exp(channel 1), straight from the pairs
     if (r.mode == 0) return exp((double)m[2 * r.lo + 1]);
@@ -221,15 +206,6 @@ GL_DEV double splitmix_u01(uint64_t seed, uint64_t i) {
     z = z ^ (z >> 31);
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
-
-struct UttDesc {  // one utterance of a batch
-    int64_t xoff;     // offset of its signal in the x / out buffers (samples)
-    int64_t fbase;    // index of its first frame in the frame-major buffers
-    int32_t frames;
-    int32_t has_x0;
-    int64_t len;      // L = N + (F-1) hop
-    uint64_t seed;
-};
 
 // Four samples per lane: utterances start 16-byte aligned and are padded to multiples of four samples (batch_create), so the padding
 // takes the (never read) extra values and every access is a full 16 / 32 bytes.
@@ -416,15 +392,6 @@ __global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, i
 // Segment boundaries: a segment OWNS the samples [s0, s0 + G*hop) (the last one of an utterance: to the utterance's
 // end).  What its frames add beyond that (N - hop samples, the next segment's head) goes to a per-segment TAIL buffer;
 // whoever reads a head sample next iteration adds x + tail (two plain loads, deterministic, no atomics).
-struct SegDesc {
-    int64_t s0;       // offset of the segment's first sample in the x buffers
-    int64_t frame0;   // global index of its first frame (row of mag / nyq)
-    int32_t G;        // frames in the segment
-    int32_t has_prev; // not the first segment of its utterance -> add tail[seg-1] over the first 16-SH rows
-    int32_t has_next; // not the last -> rows >= G*SH belong to the next segment: read x + tail[seg], write tail[seg]
-    int32_t pad_;
-};
-
 // Split-phase synchronisation of a two-wave stream through LDS (gl_fft.hpp, "exchange synchronisation"): every wave counts its own
 // events -- write burst done, read burst issued -- in a word of its own; `arrive()` publishes the count (one ds_write_b32, queued behind
 // the wave's data accesses: the LDS executes a wave's instructions in order), `wait()` polls the partner's word until it shows the same
@@ -443,15 +410,16 @@ template <bool WIDE> struct StreamFlagSync {
     }
     GL_DEV void wait() {
         if constexpr (WIDE) {
+#ifndef GL_ABL_NOPOLL   // (timing ablation, results garbage: what the polling itself costs)
             asm volatile("" ::: "memory");
             while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {}
             asm volatile("" ::: "memory");
+#endif
         }
     }
     GL_DEV void operator()() { arrive(); wait(); }
 };
 
-constexpr int kFusedThreads = 256;
 #ifndef GL_PAIRED
 #define GL_PAIRED 0   // the fused kernels' forward / inverse FFT as a pair: no synchronisation between pass 3's reads and the inverse's first writes (gl_fft.hpp)
 #endif
@@ -460,6 +428,9 @@ constexpr int kFusedThreads = 256;
 #endif
 #ifndef GL_D_MAGS_EARLY
 #define GL_D_MAGS_EARLY 0
+#endif
+#ifndef GL_D_NYQ_ONCE
+#define GL_D_NYQ_ONCE 0
 #endif
 #ifndef GL_WIN_B128
 #define GL_WIN_B128 0
@@ -505,7 +476,6 @@ constexpr bool fused_w2_regs(int n, int sh) { return !(n >= 4096 && sh <= 2); } 
 // One window read per frame (the synthesis multiply's registers serve the next frame's analysis multiply, k_gl_fused) costs ~30
 // registers around the loop's back edge: taken where no spill results (hipcc -S audit, tests/test_isa_hazards.py).
 constexpr bool fused_one_window_read(int n, int sh) { return n >= 4096 || (n == 2048 && sh != 2) || sh == 4 || sh == 8; }
-constexpr int kMaxSegFrames = 64;   // a wave fetches the Nyquist magnitudes of all its segment's frames with ONE load (lane = frame)
 
 // Lane-pair form of two consecutive rows.  A row is T sample pairs, one per lane (8 bytes): as such it moves with dwordx2
 // instructions, 512 B each, and what bounds the vector-memory path of a CU here is the NUMBER of wave-instructions it keeps in
@@ -553,7 +523,6 @@ GL_DEV v4f quad_from_rows(v2f r0, v2f r1, bool even) {
 // resident, or data that really contains the sentinel pattern -- sets *err, after which every stream runs through without
 // waiting, and the host recomputes the batch with the per-iteration kernels.
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-constexpr int kPersistMaxNb = 15;            // neighbours on each side the kernel handles: (N-1)/hop <= 15, i.e. hop >= N/16
 constexpr int kPersistAutoNb = 7;            // ... and up to which the library chooses it by itself (hop >= N/8)
 constexpr unsigned kPersistSpinTicks = 20u * 100000u;   // default spin limit: 20 ms of the 100 MHz wall clock
 constexpr unsigned kPersistSentinel = 0xffffffffu;
@@ -1580,6 +1549,16 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     load_mag_rows_d<G>(mnext, t, mag_p);
     mnext.nq = nyq_p[0];
 #endif
+    // Nyquist magnitudes of all the segment's frames: ONE vector load per wave (lane = frame, G <= kMaxSegFrames = 64) and two v_readlane
+    // per frame, as k_gl_fused does.  The per-frame scalar load it replaces returned out of order with the LDS reads, so the first
+    // counted LDS wait behind it -- at the frame's head, in front of the window reads -- became lgkmcnt(0) and sat out the scalar load's latency.
+    constexpr bool NYQ_ONCE = GL_D_NYQ_ONCE && T >= 64;
+    double nyq_all = 0.0;
+    if constexpr (NYQ_ONCE) {
+        const int l = threadIdx.x & 63;
+        nyq_all = nyq_p[l < d.G ? l : 0];
+        asm volatile("v_mov_b64 %0, %0" : "+v"(nyq_all));   // consume the load here: no vmcnt wait in front of every frame's v_readlane
+    }
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
@@ -1588,7 +1567,11 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
 #else
         MagRawD mraw;                                                         // issued now, finished after the forward FFT
         load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
-        mraw.nq = nyq_p[gg];
+        if constexpr (NYQ_ONCE) {
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, nyq_all);
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)bits, gg), hi = __builtin_amdgcn_readlane((unsigned)(bits >> 32), gg);
+            mraw.nq = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        } else mraw.nq = nyq_p[gg];
 #endif
         st.mark(16);
         // (k_gl_fused's single window read per frame was tried here too: 64 more live registers around the back edge, 3 % MORE

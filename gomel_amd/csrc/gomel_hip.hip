@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/gomel_hip.h"
+#include "gomel_host.hpp"
 #include "gl_kernels.hpp"
 
 // =============================================================================================== host side
@@ -43,69 +44,16 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
-// No C++ exception crosses the C boundary: every entry point that can allocate on the host runs inside this pair.
-#define GOMEL_TRY try {
-#define GOMEL_CATCH                                              \
-    } catch (const std::bad_alloc&) { return GOMEL_ERR_NO_MEMORY; } \
-    catch (...) { return GOMEL_ERR_NO_MEMORY; }
-
 enum { kPrecAuto = 0, kPrecFp32 = 32, kPrecFp64 = 64, kPrecSchedule = 1 };
 
-struct TableHeader {
-    uint32_t magic, version;
-    int32_t n, hop, k, hann_periodic;
-    int32_t dom_status, pad_;
-    double fmin, fmax;
-};
-static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
-
-// Device-buffer cache of one handle.  hipFree of a multi-megabyte buffer is synchronous and slow (0.6 ms of the 0.75 ms that
-// one 342-frame, 2-iteration FromMel call took host-to-host went into freeing its working set), and the Go API is one call
-// per utterance: freed buffers are kept and handed out again to requests of similar size.  Guarded by the handle's mutex.
-struct DevPool {
-    struct Block { void* p; size_t bytes; bool used; uint64_t stamp; };
-    // the allocator behind the cache: the HIP runtime in the product; gomel_debug_pool_selftest (CPU, sanitizer builds) injects host malloc
-    hipError_t (*alloc_fn)(void**, size_t) = [](void** q, size_t n) { return hipMalloc(q, n); };
-    hipError_t (*free_fn)(void*) = [](void* q) { return hipFree(q); };
-    std::vector<Block> blocks;
-    size_t cached = 0, cap = (size_t)16 << 30;  // bytes kept while unused (GOMEL_POOL_MB; 0 = no caching); the device has 288 GB
-    uint64_t clock = 0;
-    hipError_t alloc(void** out, size_t bytes) {
-        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
-        int best = -1;
-        for (size_t i = 0; i < blocks.size(); i++) {
-            const Block& k = blocks[i];
-            if (!k.used && k.bytes >= bytes && k.bytes <= bytes + bytes / 2 + 65536 && (best < 0 || k.bytes < blocks[best].bytes)) best = (int)i;
-        }
-        if (best >= 0) { blocks[best].used = true; cached -= blocks[best].bytes; *out = blocks[best].p; return hipSuccess; }
-        hipError_t e = alloc_fn(out, bytes);
-        if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = alloc_fn(out, bytes); }   // give the cache back and retry
-        if (e == hipSuccess) blocks.push_back(Block{*out, bytes, true, 0});
-        return e;
-    }
-    void release(void* p) {
-        for (Block& k : blocks)
-            if (k.p == p) { k.used = false; k.stamp = ++clock; cached += k.bytes; trim(cap); return; }
-        (void)free_fn(p);   // not ours (never happens): plain free
-    }
-    void trim(size_t keep) {   // drop the least recently released buffers until at most `keep` bytes stay cached
-        while (cached > keep) {
-            int old = -1;
-            for (size_t i = 0; i < blocks.size(); i++)
-                if (!blocks[i].used && (old < 0 || blocks[i].stamp < blocks[old].stamp)) old = (int)i;
-            if (old < 0) break;
-            (void)free_fn(blocks[old].p);
-            cached -= blocks[old].bytes;
-            blocks.erase(blocks.begin() + old);
-        }
-    }
-    void clear() {
-        for (Block& k : blocks) (void)free_fn(k.p);
-        blocks.clear(); cached = 0;
-    }
-};
+static void hip_pool_hooks(DevPool& p) {   // the allocator behind a handle's device-buffer cache
+    p.alloc_fn = [](void** q, size_t n) { return (int)hipMalloc(q, n); };
+    p.free_fn = [](void* q) { return (int)hipFree(q); };
+    p.forget_error_fn = [] { (void)hipGetLastError(); };
+}
 
 struct gomel_handle {
+    gomel_handle() { hip_pool_hooks(pool); }
     gomel_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;       // compute (and H2D)
@@ -141,123 +89,12 @@ struct gomel_handle {
     std::vector<BinRow> undo;     // [N/2]
     std::vector<BinRow> dom;      // [K]
     void* d_blob = nullptr;       // one device allocation for all tables
-    DevPool pool;                 // working buffers of batches and of the one-shot entry points
+    DevPool pool;                 // working buffers of batches and of the one-shot entry points (hipMalloc / hipFree behind it: hip_pool_hooks)
     DevTables dt{};
 };
 
 constexpr int kErrSlots = 256;
 
-static double hz_to_mel(double v) { return 1127.0 * std::log(1.0 + (v / 700.0)); }  // mel/impl.go:304-308
-static double mel_to_hz(double v) { return 700.0 * (std::exp(v / 1127.0) - 1.0); }  // mel/impl.go:298-302
-
-static int classify_row(double vallo, double valhi, bool undomel_rules, int limit, BinRow* r) {
-    double inlo, modlo = std::modf(vallo, &inlo);
-    double inhi = std::floor(valhi);
-    if (inlo < 0) { inlo = 0; modlo = 0; inhi = 0; }  // note: -0.0 < 0 is false, exactly as in Go
-    long lo = (long)inlo, hi = (long)inhi;
-    r->lo = (int32_t)lo; r->hi = (int32_t)hi; r->modlo = modlo; r->pad_ = 0; r->div = 1;
-    if (undomel_rules) {  // mel/impl.go:365-375
-        if (lo == hi) { r->mode = 0; if (lo < 0 || lo >= limit) return GOMEL_ERR_TABLE_RANGE; }
-        else if (lo + 1 == hi && hi < limit) { r->mode = 1; if (lo < 0) return GOMEL_ERR_TABLE_RANGE; }
-        else { r->mode = 2; r->div = inhi - inlo + 1; if (hi > lo && (lo < 0 || hi > limit)) return GOMEL_ERR_TABLE_RANGE; }
-    } else {  // domel, mel/impl.go:328-336
-        if (lo + 1 == hi) { r->mode = 1; if (lo < 0 || hi >= limit) return GOMEL_ERR_TABLE_RANGE; }
-        else { r->mode = 2; r->div = (double)(hi - lo + 1); if (hi > lo && (lo < 0 || hi > limit)) return GOMEL_ERR_TABLE_RANGE; }
-    }
-    return GOMEL_OK;
-}
-
-// Bounds a BinRow must meet before it is used as a device-side index: undomel rows read bands [lo, hi) or {lo, hi} of K
-// bands; domel rows read bins [lo, hi) or {lo, hi} of the N/2+1 magnitudes (channel 1 reads one bin higher).
-static bool rows_in_range(const std::vector<BinRow>& rows, int limit, bool undomel_rules) {
-    for (const BinRow& r : rows) {
-        if (r.mode < 0 || r.mode > 2 || r.lo < 0 || !std::isfinite(r.modlo) || !std::isfinite(r.div) || r.div == 0.0) return false;
-        if (r.mode == 0 && r.lo >= limit) return false;
-        if (r.mode == 1 && (r.hi < 0 || r.hi >= limit || r.lo >= limit)) return false;
-        if (r.mode == 2 && r.hi > r.lo && r.hi > limit) return false;
-        if (!undomel_rules && r.mode == 0) return false;   // domel has no copy rows
-    }
-    return true;
-}
-
-static int build_mel_tables(const gomel_config& c, std::vector<BinRow>& undo, std::vector<BinRow>& dom, int* dom_status) {
-    const int H = c.resolut / 2, K = c.num_mels;
-    const double fmin = c.mel_fmin, fmax = c.mel_fmax;
-    undo.resize(H);
-    const double filterbin = hz_to_mel(fmax) / (double)K;  // mel/impl.go:348
-    for (int i = 0; i < H; i++) {
-        double vallo = hz_to_mel(((double)i * (fmax + fmin) / (double)H) - fmin) / filterbin;
-        double valhi = hz_to_mel(((double)(i + 1) * (fmax + fmin) / (double)H) - fmin) / filterbin;
-        int rc = classify_row(vallo, valhi, true, K, &undo[i]);
-        if (rc) return rc;
-    }
-    dom.resize(K);
-    *dom_status = GOMEL_OK;
-    const double melbin = hz_to_mel(fmax) / (double)K;  // mel/impl.go:311
-    for (int i = 0; i < K; i++) {
-        double vallo = (double)H * (fmin + mel_to_hz(melbin * (double)i)) / (fmax + fmin);
-        double valhi = (double)H * (fmin + mel_to_hz(melbin * (double)(i + 1))) / (fmax + fmin);
-        int rc = classify_row(vallo, valhi, false, H, &dom[i]);
-        if (rc) { *dom_status = rc; dom[i].mode = 2; dom[i].lo = dom[i].hi = 0; dom[i].div = 1; }
-    }
-    return GOMEL_OK;
-}
-
-// Everything a handle derives from the configuration alone (no device involved): Hann, undomel rows, domel rows.
-static int build_host_tables(const gomel_config& c, std::vector<double>& window, std::vector<BinRow>& undo, std::vector<BinRow>& dom,
-                             int* dom_status) {
-    const int N = c.resolut;
-    window.resize(N);
-    const double arg = 2.0 * M_PI / (double)(c.hann_periodic ? N : N - 1);  // gossp window.CreateHanning
-    for (int i = 0; i < N; i++) window[i] = 0.5 - 0.5 * std::cos(arg * (double)i);
-    return build_mel_tables(c, undo, dom, dom_status);
-}
-
-static void pack_tables(const gomel_config& c, int dom_status, const std::vector<double>& window, const std::vector<BinRow>& undo,
-                        const std::vector<BinRow>& dom, void* blob);
-
-static int validate_config(const gomel_config* c) {
-    if (!c) return GOMEL_ERR_NULL;
-    if (c->num_mels <= 0 || c->num_mels > kMaxMels || c->window <= 0 || c->resolut <= 0 || c->griffin_lim_iterations < 0) return GOMEL_ERR_BAD_CONFIG;
-    if (c->tune_mul == 0.0 || !(c->mel_fmax + c->mel_fmin > 0.0) || !(c->mel_fmax > 0.0)) return GOMEL_ERR_BAD_CONFIG;
-    if (!gomel_supported_n(c->resolut) && !gomel_generic_n(c->resolut)) return GOMEL_ERR_UNSUPPORTED_N;
-    return GOMEL_OK;
-}
-
-// The automatic precision schedule: how many of a call's I Griffin-Lim iterations run in fp64 before the fp32 kernels take over
-// (mel/mel.go:76-139 is float64 throughout; the schedule keeps the default call within the 1e-4 RMS bar of SURVEY 8(b) at a calibrated
-// RATE -- fp64 throughout, gomel_set_precision(h, 64), is the guarantee).  Two calibrated tables (scripts/calibrate_schedule.py; how they
-// were made, and every held-out tally, is DESIGN.md section 2 / LABBOOK.md): kAutoSchedule for frames that overlap up to four-fold
-// (towav: N 4096 / hop 1280; TTS: 1024 / 256), kAutoScheduleDense from six-fold on (NewMel's defaults, mel/mel.go:30-41: 2048 / 256, eight-fold).
-// The rule is MONOTONE in the overlap Resolut / Window: between four- and six-fold k is interpolated linearly between the two tables'
-// values, rounded up (N 2048 / hop 400, 5.12-fold: 44 of 60).  Between calibrated iteration counts k is interpolated upwards; beyond the
-// last one the number of trailing fp32 iterations is held; up to five iterations run in fp64 throughout (the reference's shipped
-// GriffinLimIterations = 2, mel/mel.go:39, among them).
-// FROZEN in round 5: no table edit without a new failing full-size test (tests/test_gpu_round5.py holds the default call to < 1e-4 on
-// 256 x 400 frames at the NewMel-default geometry and on the interpolated stretch).
-struct AutoPoint { int iters, k; };
-static const AutoPoint kAutoSchedule[] = {{2, 2}, {5, 5}, {10, 6}, {20, 14}, {30, 25}, {40, 30}, {60, 35}, {100, 80}};        // overlap <= 4
-static const AutoPoint kAutoScheduleDense[] = {{2, 2}, {5, 5}, {10, 6}, {20, 16}, {30, 27}, {40, 32}, {60, 50}, {100, 90}};   // overlap >= 6
-static int auto_table_k(const AutoPoint* tab, int I) {
-    constexpr int n = (int)(sizeof kAutoSchedule / sizeof kAutoSchedule[0]);
-    static_assert(sizeof kAutoSchedule == sizeof kAutoScheduleDense, "the two tables have the same calibrated iteration counts");
-    if (I <= tab[0].iters) return std::min(I, tab[0].k);
-    for (int i = 1; i < n; i++)
-        if (I <= tab[i].iters) {
-            const AutoPoint a = tab[i - 1], b = tab[i];
-            const int k = a.k + ((b.k - a.k) * (I - a.iters) + (b.iters - a.iters) - 1) / (b.iters - a.iters);   // rounded up
-            return std::min(I, std::max(k, a.k));
-        }
-    return I - (tab[n - 1].iters - tab[n - 1].k);
-}
-static int auto_fp64_iterations(const gomel_config& c, int I) {
-    const int k_lo = auto_table_k(kAutoSchedule, I), k_hi = std::max(k_lo, auto_table_k(kAutoScheduleDense, I));
-    const int64_t N = c.resolut, hop = c.window;
-    if (hop <= 0 || N <= 4 * hop) return k_lo;                  // overlap <= 4 (hops >= Resolut included)
-    if (N >= 6 * hop) return k_hi;                              // overlap >= 6
-    const int64_t num = (int64_t)(k_hi - k_lo) * (N - 4 * hop), den = 2 * hop;   // (k_hi - k_lo) * (overlap - 4) / 2
-    return std::min(I, k_lo + (int)((num + den - 1) / den));
-}
 // fp64 iterations of a call of I iterations on this handle: 0 = fp32 throughout, >= I = fp64 throughout.  Caller holds h->mu.
 static int resolve_fp64_iterations(const gomel_handle* h, int I) {
     if (h->generic) return I;                              // the generic-length kernels are fp64
@@ -538,14 +375,6 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
 // registration (range pinned by somebody else, partial overlap, memory that cannot be locked, ...) leaves that buffer pageable:
 // the runtime then stages the copy itself.  gomel_host_register / gomel_host_alloc (below) let a caller that reuses its
 // buffers pay the registration once instead of per call.
-// What the registry asks of the runtime.  The product's backend is HIP; gomel_debug_pin_backend(1) swaps in an in-process fake that
-// records registrations and counts contract violations (overlapping registrations, unregistering what is not registered), so that the
-// interval logic and its locking can be exercised -- under AddressSanitizer / ThreadSanitizer -- on a machine without a GPU.
-struct PinBackend {
-    bool (*foreign)(void* p, uintptr_t* base, size_t* size);   // pinned / device memory somebody else owns?  (its allocation's extent)
-    bool (*reg)(void* p, size_t bytes);
-    void (*unreg)(void* p);
-};
 static bool hip_pin_foreign(void* p, uintptr_t* base, size_t* size) {
     hipPointerAttribute_t at;
     *base = 0; *size = 0;
@@ -565,79 +394,22 @@ static bool hip_pin_reg(void* p, size_t bytes) {
 }
 static void hip_pin_unreg(void* p) { (void)hipHostUnregister(p); (void)hipGetLastError(); }
 static const PinBackend kHipPins = {hip_pin_foreign, hip_pin_reg, hip_pin_unreg};
-
-struct PinRegistry {
-    struct Entry { size_t bytes; int users; };
-    const PinBackend* be = &kHipPins;
-    std::mutex mu;
-    std::map<uintptr_t, Entry> live;   // base -> extent, users
-    // Ranges found pinned (or device memory) by somebody else -- gomel_host_alloc / hipHostMalloc buffers a bulk caller reuses.
-    // Asking the runtime costs ~10-20 us per pointer (hipPointerGetAttributes), 5-10 ms for the 768 buffers of a 256-utterance
-    // call; the answer is remembered per allocation.  A stale entry (buffer freed, address reused by pageable memory) only
-    // means that buffer is not pinned for the call: slower copy, same result.
-    std::map<uintptr_t, size_t> foreign;   // allocation base -> size
-    // returns the base of the registration that now covers [p, p+bytes) (a token for release), or 0
-    uintptr_t acquire(void* p, size_t bytes) {
-        const uintptr_t a = (uintptr_t)p;
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = live.upper_bound(a);
-        if (it != live.begin()) {
-            auto pr = std::prev(it);
-            if (a + bytes <= pr->first + pr->second.bytes) { pr->second.users++; return pr->first; }   // inside a live registration
-            if (a < pr->first + pr->second.bytes) return 0;                                          // straddles its end
-        }
-        if (it != live.end() && it->first < a + bytes) return 0;                                      // runs into the next one
-        {
-            auto f = foreign.upper_bound(a);
-            if (f != foreign.begin()) { auto pf = std::prev(f); if (a + bytes <= pf->first + pf->second) return 0; }
-        }
-        uintptr_t fbase = 0; size_t fsize = 0;
-        if (be->foreign(p, &fbase, &fsize)) {
-            if (fbase && fsize) {
-                if (foreign.size() > 65536) foreign.clear();
-                foreign[fbase] = fsize;
-            }
-            return 0;
-        }
-        if (!be->reg(p, bytes)) return 0;
-        live.emplace(a, Entry{bytes, 1});
-        return a;
-    }
-    void release(uintptr_t base) {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = live.find(base);
-        if (it == live.end()) return;
-        if (--it->second.users == 0) {
-            be->unreg((void*)base);
-            live.erase(it);
-        }
-    }
-};
-static PinRegistry g_pins;
+static const bool g_hip_pins_installed = (g_pins.be = g_pins.product_be = &kHipPins, true);   // at load time: the product's backend
 
 // The buffers of ONE call.  want() only records (base, longest extent asked for) -- prefix views buf[:a], buf[:b] of one base
 // become one registration of max(a, b) bytes -- and commit() registers.  The destructor first drains the streams the call
 // copied on (every early error return still has copies queued), then drops the references.
-struct PinnedScope {
-    std::vector<std::pair<void*, size_t>> wanted;
-    std::vector<uintptr_t> held;
+struct PinnedScope : PinWants {
     hipStream_t drain[2] = {nullptr, nullptr}, extra = nullptr;
-    void want(const void* p, size_t bytes) {
-        if (!p || bytes < (1u << 20)) return;
-        void* q = const_cast<void*>(p);
-        for (auto& w : wanted) if (w.first == q) { w.second = std::max(w.second, bytes); return; }
-        wanted.emplace_back(q, bytes);
-    }
     void commit(hipStream_t s0 = nullptr, hipStream_t s1 = nullptr) {
         drain[0] = s0; drain[1] = s1;
-        for (auto& w : wanted) if (uintptr_t t = g_pins.acquire(w.first, w.second)) held.push_back(t);
-        wanted.clear();
+        PinWants::commit();
     }
     void drain_too(hipStream_t s) { extra = s; }
     ~PinnedScope() {
         if (held.empty()) return;
         for (hipStream_t s : {drain[0], drain[1], extra}) if (s) { (void)hipStreamSynchronize(s); (void)hipGetLastError(); }
-        for (uintptr_t t : held) g_pins.release(t);
+        release_all();
     }
 };
 
@@ -697,8 +469,6 @@ struct gomel_batch {
     size_t ctl_bytes = 0;
 };
 
-// magnitudes per frame the exported ISTFT reads: bins 0 ... N/2, and bin N/2+1 as well when N is odd (both top bins lie outside the conjugate fill)
-static inline size_t istft_row(int N) { return (size_t)(N / 2 + 1 + (N & 1)); }
 static inline hipStream_t run_stream(const gomel_batch* b) { return b->rs ? b->rs : b->h->stream; }
 static void persist_release(gomel_batch* b);
 static void gate_forget(gomel_batch* b);
@@ -723,32 +493,6 @@ struct BatchGuard {   // frees a half-built batch on every early exit, exception
     ~BatchGuard() { if (b) batch_free(b); }
 };
 
-// The fused kernel needs hop = SH * (N/16) with SH in the instantiated set.
-static int fused_shift(const gomel_config& c) {
-    if (!gomel_supported_n(c.resolut)) return 0;          // generic-length path: gl_any.hpp kernels only
-    const int row = c.resolut / 16;
-    if (c.window % row) return 0;
-    const int sh = c.window / row;
-    return (sh == 1 || sh == 2 || sh == 4 || sh == 5 || sh == 8) ? sh : 0;
-}
-// Every other even hop below N: k_gl_fused_any (the same sliding window, shifted through LDS).  gmin = frames a stream must walk so
-// that what it adds past its own samples reaches into the next segment only.
-static int fused_gmin(const gomel_config& c) { return c.window > 0 ? (c.resolut - 1) / c.window : 0; }   // ceil((N - hop) / hop)
-static bool fused_any_ok(const gomel_config& c) {
-    return gomel_supported_n(c.resolut) && c.window > 0 && c.window < c.resolut && fused_gmin(c) <= 31;
-}
-static int fused_kind(const gomel_config& c) {   // 1 k_gl_fused, 2 k_gl_fused_any
-    static const bool prefer_any = getenv("GOMEL_FORCE_ANY") != nullptr;   // A/B knob: the any-hop kernel at an aligned hop
-    if (prefer_any && fused_any_ok(c)) return 2;
-    return fused_shift(c) ? 1 : fused_any_ok(c) ? 2 : 0;
-}
-static bool fused_applicable(const gomel_config& c) { return fused_kind(c) != 0; }
-
-// The persistent kernel (k_gl_persist) wants 16-byte quads that never straddle a hop (hop and N multiples of 4), at most
-// kPersistMaxNb neighbours on each side, and one of the register FFT cores.
-static bool persist_geometry_ok(const gomel_config& c) {
-    return gomel_supported_n(c.resolut) && c.window % 4 == 0 && c.window > 0 && (c.resolut - 1) / c.window <= kPersistMaxNb;
-}
 template <int N, int OCC> static int persist_census_n(int device) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persist<N, OCC, (OCC == 1 ? 4 : 2)>, 128, 0) != hipSuccess ||
@@ -779,68 +523,6 @@ static int persist_census(gomel_handle* h, int occ) {   // occ 1 / 2: the fp32 k
         c = n;
     }
     return c;
-}
-
-// Batch size (total frames) from which the fused kernel beats the generic pair.  A fused stream walks at least gmin =
-// ceil((16-SH)/SH) frames one after the other, so a launch never takes less than gmin frame latencies, while the generic kernels
-// run every frame in parallel: measured crossovers for gmin = 3 (scripts/cross_probe2.py, 60 iterations, one launch per
-// iteration): 1.5 k frames at N 4096, 2.5 k at 2048, 3 k at 1024, 6 k at 512, 12 k at 256; scaled with gmin.
-// With fp64 iterations in the call (default mode, 64-bit mode) the crossovers lie elsewhere (scripts/size_sweep.py GEOM 400 1|2 ..., profiles/r04/
-// size_sweep_paths.txt; default mode, 60 iterations): N 4096 ~2 000 frames, N 2048 / hop 256 ~4 200 (gmin 7: the fp64 fused launch is flat at
-// 3.1-3.3 ms up to a full round of 6 400 frames, the generic pair passes that at 4 000), N 1024 ~4 500, N 512 ~7 500, N 256 ~15 000.
-static int64_t fused_min_frames(const gomel_config& c, bool fp64_iterations = false) {
-    if (!fused_kind(c)) return INT64_MAX;
-    const int64_t base = fp64_iterations ? (c.resolut >= 4096 ? 2048 : c.resolut == 2048 ? 1800 : c.resolut == 1024 ? 4500 : c.resolut == 512 ? 7500 : 15000)
-                                         : (c.resolut >= 4096 ? 1536 : c.resolut == 2048 ? 2560 : c.resolut == 1024 ? 3072 : c.resolut == 512 ? 6144 : 12288);
-    return base * std::max(1, fused_gmin(c)) / 3;
-}
-
-// Segment plan of the fused kernel.  What matters (scripts/chunk_probe.py): segments of 25-40 frames amortise the 16-row
-// prologue and the workgroup's table fill, and the NUMBER of segments should fill whole rounds of the chip: a workgroup takes
-// STREAMS segments and 2 workgroups fit a CU, so one round is 512 workgroups; 533 workgroups cost two rounds (1.75 M frames/s
-// where 512 reach 1.95 M on the same 12 800 frames).  So: pick the number of rounds r for ~50 frames per segment, aim at
-// r * 512 * STREAMS segments in total, and give each utterance its share in proportion to its frames.
-static void plan_segments(gomel_batch* b) {
-    const gomel_config& c = b->h->cfg;
-    const int gmin = std::max(1, fused_gmin(c));
-    const int streams = kFusedThreads / (c.resolut / 32);                      // segments per workgroup (T = N/32 lanes per stream)
-    const int64_t per_round = (int64_t)512 * streams;
-    // ~50 frames per segment where the batch gives two rounds or more (fewer 16-row prologues and table fills: 2 rounds of 50 beat
-    // 4 of 25 by 1 % at config 3, scripts/seg_probe.sh), never above 60 (the kernel's limit is kMaxSegFrames = 64)
-    int64_t rounds = std::max<int64_t>(1, (b->total_frames + 25 * per_round) / (50 * per_round));
-    while (b->total_frames > rounds * per_round * 60) rounds++;
-    double target = (double)(rounds * per_round);                              // segments wanted in total
-    int forced = 0;
-    if (const char* e = getenv("GOMEL_SEG_FRAMES")) { int v = atoi(e); if (v > 0) forced = std::min(std::max(v, gmin), kMaxSegFrames); }  // tuning knob
-    b->segs.clear();
-    b->g_max = 0;
-    int64_t frames_done = 0;
-    double segs_done = 0;
-    for (const UttDesc& u : b->utts) {
-        int nseg;
-        if (forced) nseg = std::max(1, (u.frames + forced / 2) / forced);
-        else {   // this utterance's share of the target, carried over utterances so that the total lands on it
-            const double want = target * (double)(frames_done + u.frames) / (double)b->total_frames - segs_done;
-            nseg = std::max(1, (int)std::llround(want));
-        }
-        while (nseg > 1 && u.frames / nseg < gmin) nseg--;
-        // hard cap kMaxSegFrames frames per segment (k_gl_fused keeps one Nyquist magnitude per lane); it wins over gmin, which
-        // only matters for has_next segments of very short utterances and gmin <= 15 < 64 / 2 always leaves room
-        nseg = std::max(nseg, (u.frames + kMaxSegFrames - 1) / kMaxSegFrames);
-        frames_done += u.frames; segs_done += nseg;
-        const int base = u.frames / nseg, rem = u.frames % nseg;
-        int f0 = 0;
-        for (int s = 0; s < nseg; s++) {
-            SegDesc d;
-            d.G = base + (s < rem ? 1 : 0);
-            d.s0 = u.xoff + (int64_t)f0 * c.window;
-            d.frame0 = u.fbase + f0;
-            d.has_prev = s > 0; d.has_next = s + 1 < nseg; d.pad_ = 0;
-            b->segs.push_back(d);
-            b->g_max = std::max(b->g_max, d.G);
-            f0 += d.G;
-        }
-    }
 }
 
 template <int N, int SH> static void launch_fused_t(gomel_batch* b, int cur) {
@@ -957,27 +639,16 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm);
 //     enqueued while persistent launches are in flight first makes its stream wait for them (hipStreamWaitEvent: <= 0.6 ms of
 //     device-side ordering, nothing blocks on the host).  The gate's mutex is held while a persistent launch is being enqueued
 //     (~0.1 ms), so that "nothing else in flight" still holds when its kernel reaches the queue.
-struct DeviceGate {
-    struct Ent { hipEvent_t ev; const gomel_batch* owner; };
-    std::mutex mu;
-    int persist_units = 0;      // 1/1024ths of the device taken by queued persistent launches
-    int enqueueing = 0;         // ordinary runs that have entered the gate and not yet recorded their event
-    std::vector<Ent> np;        // events behind ordinary kernel work in flight
-    std::vector<Ent> ps;        // events behind persistent launches in flight
-    static void prune(std::vector<Ent>& v) {   // caller holds mu; drops what has completed
-        size_t k = 0;
-        for (size_t i = 0; i < v.size(); i++) {
-            const hipError_t e = hipEventQuery(v[i].ev);
-            if (e == hipErrorNotReady) v[k++] = v[i];
-            else if (e != hipSuccess) (void)hipGetLastError();
-        }
-        v.resize(k);
-    }
-    static void put(std::vector<Ent>& v, hipEvent_t ev, const gomel_batch* owner) {
-        for (const Ent& e : v) if (e.ev == ev) return;   // re-recorded: the entry now stands for the latest record
-        v.push_back(Ent{ev, owner});
+struct HipEvOps {
+    typedef hipEvent_t Event;
+    static int query(hipEvent_t ev) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipErrorNotReady) return 1;
+        if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+        return 0;
     }
 };
+typedef DeviceGateT<HipEvOps> DeviceGate;
 static DeviceGate g_gate[64];
 static inline DeviceGate& gate_of(const gomel_handle* h) { return g_gate[h->device & 63]; }
 
@@ -1351,7 +1022,7 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     const int N = h->cfg.resolut;
     const size_t in_b = n_frames * (inverse ? (size_t)(N + 2) : (size_t)N) * 4, out_b = n_frames * (inverse ? (size_t)N : (size_t)(N + 2)) * 4;
     float *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(h->pool.alloc((void**)&d_in, in_b));
+    HIPCHK((hipError_t)h->pool.alloc((void**)&d_in, in_b));
     if (h->pool.alloc((void**)&d_out, out_b) != hipSuccess) { h->pool.release(d_in); return GOMEL_ERR_HIP; }
     int rc = GOMEL_OK;
     if (hipMemcpyAsync(d_in, in, in_b, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = GOMEL_ERR_HIP;
@@ -1365,54 +1036,15 @@ static int fft_hook(gomel_handle* h, bool inverse, const float* in, size_t n_fra
     return rc;
 }
 
-static void pack_tables(const gomel_config& c, int dom_status, const std::vector<double>& window, const std::vector<BinRow>& undo,
-                        const std::vector<BinRow>& dom, void* blob) {
-    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, c.resolut, c.window, c.num_mels, c.hann_periodic, dom_status, 0, c.mel_fmin, c.mel_fmax};
-    char* p = (char*)blob;
-    memcpy(p, &th, sizeof th); p += sizeof th;
-    memcpy(p, window.data(), window.size() * 8); p += window.size() * 8;
-    memcpy(p, undo.data(), undo.size() * sizeof(BinRow)); p += undo.size() * sizeof(BinRow);
-    memcpy(p, dom.data(), dom.size() * sizeof(BinRow));
-}
-
 // =============================================================================================== C ABI
 extern "C" {
 
-int gomel_abi_version(void) { return GOMEL_HIP_ABI_VERSION; }
 int gomel_last_hip_error(void) { return g_last_hip; }
 
 int gomel_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
-
-const char* gomel_strerror(int s) {
-    switch (s) {
-        case GOMEL_OK: return "ok";
-        case GOMEL_ERR_BAD_CONFIG: return "bad configuration (NumMels/Window/Resolut/TuneMul/MelFmax)";
-        case GOMEL_ERR_UNSUPPORTED_N: return "Resolut not covered: any length from 4 to 65536 is (FFT test hooks, target magnitudes and package phase: 256 ... 4096, powers of two)";
-        case GOMEL_ERR_BAD_LENGTH: return "spectrogram length is not a multiple of NumMels";
-        case GOMEL_ERR_EMPTY: return "empty input";
-        case GOMEL_ERR_TABLE_RANGE: return "mel table indexes outside the band/bin range for this configuration";
-        case GOMEL_ERR_BUFFER_TOO_SMALL: return "output buffer too small";
-        case GOMEL_ERR_NULL: return "null pointer or call out of order";
-        case GOMEL_ERR_HIP: return "HIP runtime error (see gomel_last_hip_error)";
-        case GOMEL_ERR_NO_DEVICE: return "no usable HIP device";
-        case GOMEL_ERR_BAD_TABLES: return "table blob does not match the configuration";
-        case GOMEL_ERR_TOO_SHORT: return "padded input shorter than one frame";
-        case GOMEL_ERR_NO_MEMORY: return "host allocation failed";
-        case GOMEL_ERR_BUSY: return "handle busy: submitted jobs have not been waited for";
-        default: return "unknown status";
-    }
-}
-
-int gomel_default_config(gomel_config* c) {
-    if (!c) return GOMEL_ERR_NULL;
-    c->num_mels = 160; c->window = 256; c->resolut = 2048; c->griffin_lim_iterations = 2;  // mel/mel.go:30-41
-    c->mel_fmin = 0; c->mel_fmax = 8000; c->tune_mul = 1; c->tune_add = 0;
-    c->device = -1; c->hann_periodic = 0;
-    return GOMEL_OK;
 }
 
 int gomel_create(const gomel_config* cfg, gomel_handle** out) { GOMEL_TRY return create_common(cfg, nullptr, 0, out); GOMEL_CATCH }
@@ -1432,27 +1064,6 @@ int gomel_tables_export(const gomel_handle* h, void* blob, size_t cap) {
     std::lock_guard<std::mutex> lk(const_cast<gomel_handle*>(h)->mu);   // gomel_set_window may be replacing the window
     pack_tables(h->cfg, h->dom_status, h->window, h->undo, h->dom, blob);
     return GOMEL_OK;
-}
-
-size_t gomel_tables_bytes_for(const gomel_config* c) {
-    if (validate_config(c) != GOMEL_OK) return 0;
-    return sizeof(TableHeader) + (size_t)c->resolut * 8 + ((size_t)c->resolut / 2 + c->num_mels) * sizeof(BinRow);
-}
-
-int gomel_tables_build(const gomel_config* cfg, void* blob, size_t cap) {
-    if (!cfg || !blob) return GOMEL_ERR_NULL;
-    int rc = validate_config(cfg);
-    if (rc) return rc;
-    if (cap < gomel_tables_bytes_for(cfg)) return GOMEL_ERR_BUFFER_TOO_SMALL;
-    GOMEL_TRY
-    std::vector<double> window;
-    std::vector<BinRow> undo, dom;
-    int dom_status = GOMEL_OK;
-    rc = build_host_tables(*cfg, window, undo, dom, &dom_status);
-    if (rc) return rc;
-    pack_tables(*cfg, dom_status, window, undo, dom, blob);
-    return GOMEL_OK;
-    GOMEL_CATCH
 }
 
 static int set_window_guarded(gomel_handle* h, const double* w, size_t n) {
@@ -1506,11 +1117,6 @@ int gomel_set_precision_schedule(gomel_handle* h, int32_t fp64_iterations) {
     else { h->precision = kPrecSchedule; h->precise_iters = fp64_iterations; }
     return GOMEL_OK;
 }
-int32_t gomel_auto_fp64_iterations(const gomel_config* cfg, int32_t iterations) {
-    if (!cfg || iterations <= 0) return 0;
-    if (!gomel_supported_n(cfg->resolut)) return iterations;   // generic-length kernels: fp64
-    return auto_fp64_iterations(*cfg, iterations);
-}
 int gomel_get_precision(const gomel_handle* h, int32_t iterations, int32_t* fp64_iterations) {
     if (!h || !fp64_iterations) return GOMEL_ERR_NULL;
     if (iterations < 0) iterations = h->cfg.griffin_lim_iterations;
@@ -1542,27 +1148,6 @@ int gomel_device_name(const gomel_handle* h, char* buf, size_t cap) {
     HIPCHK(hipGetDeviceProperties(&p, h->device));
     snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
     return GOMEL_OK;
-}
-
-size_t gomel_out_len(const gomel_config* c, size_t n_pairs) {
-    if (!c || c->num_mels <= 0 || n_pairs == 0 || n_pairs % (size_t)c->num_mels) return 0;
-    return (size_t)c->resolut + (n_pairs / (size_t)c->num_mels - 1) * (size_t)c->window;  // mel/mel.go:80
-}
-
-size_t gomel_pad_len(size_t n, int32_t window) {  // mel/impl.go:429-455
-    if (window <= 0) return n;
-    size_t mint = 15 * (size_t)window, padlen = 0;
-    if (n >= mint) {
-        size_t rem = (n - mint) % (size_t)window;
-        if (rem != 0) padlen = (size_t)window - rem - 1;
-    } else {
-        padlen = mint - n - 1;
-    }
-    return n + padlen;
-}
-
-int gomel_is_padded(size_t orig, size_t padded, int32_t window) {  // mel/impl.go:457-479
-    return gomel_pad_len(orig, window) == padded ? 1 : 0;
 }
 
 // One plan for both kinds of input: log-mel pairs (n_pairs[u] = frames * NumMels) or, for gomel_istft, linear magnitudes
@@ -1687,7 +1272,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
         alloc((void**)&b->d_xd[0], (size_t)b->total_len * 8);
         alloc((void**)&b->d_xd[1], (size_t)b->total_len * 8);
         if (b->fast) {   // fp64 fused kernel: segments and tails as in the fp32 case, no per-frame output buffer
-            plan_segments(b);
+            plan_segments(b->h->cfg, b->utts, b->total_frames, b->segs, b->g_max);
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
             alloc((void**)&b->d_taild[0], b->segs.size() * (size_t)(N - hop) * 8);
             alloc((void**)&b->d_taild[1], b->segs.size() * (size_t)(N - hop) * 8);
@@ -1738,7 +1323,7 @@ static int batch_create_common(gomel_handle* h, size_t n_utt, const size_t* n_pa
             alloc((void**)&b->d_frame_utt, (size_t)b->total_frames * 4);
         }
         if (b->fast) {
-            plan_segments(b);
+            plan_segments(b->h->cfg, b->utts, b->total_frames, b->segs, b->g_max);
             alloc((void**)&b->d_segs, b->segs.size() * sizeof(SegDesc));
             alloc((void**)&b->d_tail[0], b->segs.size() * (size_t)(N - hop) * 4);
             alloc((void**)&b->d_tail[1], b->segs.size() * (size_t)(N - hop) * 4);
@@ -1775,7 +1360,7 @@ static int batch_upload_impl(gomel_batch* b, const void* const* mel, const void*
         b->utts[u].seed = seeds ? seeds[u] : (uint64_t)u;
         b->any_x0 |= b->utts[u].has_x0 != 0;
     }
-    if (b->any_x0 && !b->d_x0) HIPCHK(h->pool.alloc((void**)&b->d_x0, (size_t)b->total_len * esz));
+    if (b->any_x0 && !b->d_x0) HIPCHK((hipError_t)h->pool.alloc((void**)&b->d_x0, (size_t)b->total_len * esz));
     PinnedScope pins;
     const size_t row = b->direct ? istft_row(h->cfg.resolut) : 2;   // elements per input unit (magnitude row / pair)
     if (pin_here)
@@ -1865,80 +1450,6 @@ int gomel_batch_destroy(gomel_batch* b) {
 // `heavy`: the call runs fp64 iterations (precision schedule / 64-bit mode) -- its kernels take 1.75-2.4x as long per frame while its copies
 // stay the same, so chunks twice the size still hide them and pay half the chunk-sized launches: 75.8 ms against 79.0 per 256 x 400-frame
 // call in the default mode (scripts/chunk_sweep_default.py, profiles/r04/chunk_sweep_default.txt).
-static std::vector<size_t> plan_chunks(const gomel_config& cfg, size_t n_utt, const size_t* n_pairs, bool heavy) {
-    const int K = cfg.num_mels;
-    int64_t total_frames = 0;
-    for (size_t u = 0; u < n_utt; u++) total_frames += (int64_t)(n_pairs[u] / (size_t)K);
-    // Chunk plan (scripts/chunk_plans.sh, 256 x 400 frames host to host): m full-size chunks' worth of frames, cut as
-    // half : full x (m-1) : half -- the half-size first chunk starts the GPU sooner, the half-size last one leaves less download
-    // exposed at the end (T geometry: 44.3 ms against 45.6 for eight equal chunks, with m = 8).  A full chunk is ~12k frames at
-    // Resolut 4096 (half a round of the chip, 85 us per launch) and ~32k below (shorter frames: the same launch time; at the TTS
-    // geometry three full chunks' worth, 13.5 ms, against 16.1 for eight equal chunks).  More, smaller chunks pay launch overhead and
-    // per-segment prologues; fewer expose more of the first upload and the last download.
-    const int64_t kMinChunkFrames = (cfg.resolut >= 4096 ? 12288 : 32768) * (heavy ? 2 : 1);
-    const int m_full = (int)std::min<int64_t>(16, std::max<int64_t>(1, total_frames / kMinChunkFrames));
-    int n_chunks = total_frames < kMinChunkFrames ? 1 : m_full + 1;
-    std::vector<double> shares;   // relative chunk sizes
-    if (n_chunks > 1) { shares.assign((size_t)n_chunks, 2.0); shares.front() = shares.back() = 1.0; }
-    if (const char* e = getenv("GOMEL_CHUNKS")) { int v = atoi(e); if (v > 0) { n_chunks = std::min(v, 64); shares.assign((size_t)n_chunks, 1.0); } }   // tuning knobs: equal chunks ...
-    if (const char* e = getenv("GOMEL_CHUNK_SHARES")) {                                                                                          // ... or any plan, "1,2,4,2,1"
-        std::vector<double> sv;
-        for (const char* p = e; *p;) { char* q; const double v = strtod(p, &q); if (q == p) break; if (v > 0) sv.push_back(v); p = *q ? q + 1 : q; }
-        if (sv.size() >= 1 && sv.size() <= 64) { shares = sv; n_chunks = (int)sv.size(); }
-    }
-    n_chunks = (int)std::min<size_t>((size_t)n_chunks, n_utt);
-    if ((int)shares.size() != n_chunks) shares.assign((size_t)n_chunks, 1.0);
-    double share_sum = 0;
-    for (double v : shares) share_sum += v;
-    std::vector<size_t> bounds(1, 0);
-    {
-        // A fused launch lasts as long as its longest segment, ceil(frames / segments of its rounds): a chunk just BELOW a multiple
-        // of a round's segment count uses every stream to the end, one just above it leaves them idle for most of a frame (33
-        // utterances of 400 frames per launch: 6.26 ns per frame; 32: 6.40; 17: 7.44; 16: 7.86 -- scripts/launch_scaling.py).  Each
-        // boundary is therefore moved by up to two utterances to where the chunk it closes fills its rounds best.
-        std::vector<int64_t> pre(n_utt + 1, 0);
-        for (size_t u = 0; u < n_utt; u++) pre[u + 1] = pre[u] + (int64_t)(n_pairs[u] / (size_t)K);
-        const int64_t round0 = fused_applicable(cfg) ? (int64_t)512 * (kFusedThreads / (cfg.resolut / 32)) : 0;
-        auto fill = [&](int64_t F) {   // fraction of the launch's stream-time that does work (plan_segments' rounds rule)
-            if (round0 == 0 || F <= 0) return 1.0;
-            int64_t rnd = std::max<int64_t>(1, (F + 25 * round0) / (50 * round0));
-            while (F > rnd * round0 * 60) rnd++;
-            const int64_t slots = rnd * round0;
-            return (double)F / (double)(slots * ((F + slots - 1) / slots));
-        };
-        size_t u = 0;
-        double cum = 0;
-        for (int c = 1; c < n_chunks; c++) {
-            cum += shares[(size_t)c - 1];
-            const int64_t target = (int64_t)((double)total_frames * cum / share_sum);
-            while (u < n_utt && pre[u] < target) u++;
-            size_t best = std::max(u, bounds.back() + 1);
-            if (!getenv("GOMEL_CHUNK_SHARES") && !getenv("GOMEL_CHUNKS")) {
-                const int64_t want = pre[best] - pre[bounds.back()];
-                double best_fill = fill(want);
-                for (int dlt = -2; dlt <= 2; dlt++) {
-                    const int64_t cand = (int64_t)best + dlt;
-                    if (dlt == 0 || cand <= (int64_t)bounds.back() || cand >= (int64_t)n_utt) continue;
-                    const int64_t F = pre[(size_t)cand] - pre[bounds.back()];
-                    if (F * 100 < want * 85 || F * 100 > want * 120) continue;
-                    if (fill(F) > best_fill + 0.004) { best_fill = fill(F); u = (size_t)cand; }
-                }
-                if (best_fill > fill(want)) best = u;
-            }
-            u = best;
-            bounds.push_back(best);
-        }
-        bounds.push_back(n_utt);
-        for (size_t i = 1; i < bounds.size(); i++) if (bounds[i] <= bounds[i - 1] || bounds[i] > n_utt) { bounds.assign({0, n_utt}); break; }
-        n_chunks = (int)bounds.size() - 1;
-    }
-    return bounds;
-}
-
-// Host buffers in, host buffers out.  Big batches are cut into chunks of contiguous utterances and pipelined over three
-// streams: chunk c+1's log-mel goes up (up_stream) while chunk c computes (stream) and chunk c-1's waveforms come down
-// (copy_stream); PCIe is full duplex, so with pinned host buffers the wall time is the compute time plus the first upload and
-// the last download.  Caller buffers that are not already pinned (gomel_host_alloc / gomel_host_register) are pinned for the call.
 static int from_mel_batch_chunked(gomel_handle* h, size_t n_utt, const void* const* mel, const size_t* n_pairs, const void* const* x0,
                                   const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
     if (!h || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
@@ -2282,7 +1793,6 @@ static int istft_guarded(gomel_handle* h, const double* mags, size_t n_frames, i
     return rc;
 }
 
-size_t gomel_istft_row_len(const gomel_config* cfg) { return (cfg && cfg->resolut > 0) ? istft_row(cfg->resolut) : 0; }
 int gomel_rfft_frames(gomel_handle* h, const float* frames, size_t n_frames, float* spectrum) { return fft_hook(h, false, frames, n_frames, spectrum); }
 int gomel_irfft_frames(gomel_handle* h, const float* spectrum, size_t n_frames, float* frames) { return fft_hook(h, true, spectrum, n_frames, frames); }
 
@@ -2323,16 +1833,6 @@ static int target_magnitudes_guarded(gomel_handle* h, const double* mel, size_t 
     return rc;
 }
 
-size_t gomel_to_mel_pairs(const gomel_config* c, size_t n) {
-    if (!c || c->window <= 0 || c->resolut <= 0 || c->num_mels <= 0) return 0;
-    size_t p = gomel_pad_len(n, c->window);
-    if (p < (size_t)c->resolut) return 0;
-    long F = (long)((double)(p - (size_t)c->resolut) / (double)c->window) + 1;  // gossp NumFrames
-    return (size_t)F * (size_t)c->num_mels;
-}
-
-// (*Mel).ToMel for many waveforms in one go: every utterance padded as mel/impl.go:429-455 does, all frames through one STFT
-// launch and one domel launch, log-mel pairs back per utterance.  The single-utterance entry point is the n_utt = 1 case.
 static int to_mel_batch_guarded(gomel_handle* h, size_t n_utt, const double* const* wave, const size_t* n_samples, double* const* out_pairs,
                                 const size_t* cap_pairs, size_t* n_pairs_out) {
     if (!h || !wave || !n_samples || !out_pairs) return GOMEL_ERR_NULL;
@@ -2442,20 +1942,6 @@ static int to_mel_guarded(gomel_handle* h, const double* wave, size_t n, double*
 }
 
 // ----------------------------------------------------------------------------------------------- package phase
-size_t gomel_phase_pairs(const gomel_config* c, int32_t num_freqs, size_t n) {   // len(ToPhase(buf))
-    if (!c || c->window <= 0 || c->resolut <= 0 || num_freqs <= 0) return 0;
-    size_t p = gomel_pad_len(n, c->window);
-    if (p < (size_t)c->resolut) return 0;
-    long F = (long)((double)(p - (size_t)c->resolut) / (double)c->window) + 1;
-    size_t nf = (size_t)std::min<int64_t>(num_freqs, c->resolut / 2);
-    return (size_t)F * nf;
-}
-
-size_t gomel_phase_out_len(const gomel_config* c, int32_t num_freqs, size_t n_pairs) {
-    if (!c || num_freqs <= 0 || n_pairs == 0 || n_pairs % (size_t)num_freqs) return 0;
-    return (size_t)c->resolut + (n_pairs / (size_t)num_freqs - 1) * (size_t)c->window;
-}
-
 static int to_phase_guarded(gomel_handle* h, int32_t num_freqs, const double* wave, size_t n, double* out_pairs, size_t cap_pairs, size_t* n_pairs) {
     if (!h || !wave || !out_pairs) return GOMEL_ERR_NULL;
     if (h->generic) return GOMEL_ERR_UNSUPPORTED_N;   // register FFT cores only (Resolut 256 ... 4096, powers of two)
@@ -2550,94 +2036,6 @@ int gomel_debug_persist_state(gomel_handle* h, long long set_ticks, unsigned* ba
     if (paused_for) *paused_for = h->persist_retry_at > h->batches_seen ? h->persist_retry_at - h->batches_seen : 0;
     return GOMEL_OK;
 }
-// ---- diagnostics for the host-side logic (not in the header; tests/host_stress.cpp and the sanitizer runs reach them by name) ----
-// A fake pin backend: registrations live in a map of its own; overlapping registrations and unknown unregistrations are VIOLATIONS of
-// what the registry promises the runtime.
-static std::mutex g_fake_mu;
-static std::map<uintptr_t, size_t> g_fake_regs;
-static std::atomic<long> g_fake_violations{0}, g_fake_calls{0};
-static bool fake_pin_foreign(void*, uintptr_t* base, size_t* size) { *base = 0; *size = 0; return false; }
-static bool fake_pin_reg(void* p, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_fake_mu);
-    g_fake_calls++;
-    const uintptr_t a = (uintptr_t)p;
-    auto it = g_fake_regs.upper_bound(a);
-    if (it != g_fake_regs.begin()) { auto pr = std::prev(it); if (a < pr->first + pr->second) { g_fake_violations++; return false; } }
-    if (it != g_fake_regs.end() && it->first < a + bytes) { g_fake_violations++; return false; }
-    g_fake_regs[a] = bytes;
-    return true;
-}
-static void fake_pin_unreg(void* p) {
-    std::lock_guard<std::mutex> lk(g_fake_mu);
-    g_fake_calls++;
-    if (g_fake_regs.erase((uintptr_t)p) != 1) g_fake_violations++;
-}
-static const PinBackend kFakePins = {fake_pin_foreign, fake_pin_reg, fake_pin_unreg};
-int gomel_debug_pin_backend(int fake) {   // only while nothing is registered
-    std::lock_guard<std::mutex> lk(g_pins.mu);
-    if (!g_pins.live.empty()) return GOMEL_ERR_BAD_CONFIG;
-    g_pins.be = fake ? &kFakePins : &kHipPins;
-    g_pins.foreign.clear();
-    return GOMEL_OK;
-}
-int gomel_debug_pin_stats(long* live_registry, long* live_backend, long* violations, long* backend_calls) {
-    { std::lock_guard<std::mutex> lk(g_pins.mu); if (live_registry) *live_registry = (long)g_pins.live.size(); }
-    { std::lock_guard<std::mutex> lk(g_fake_mu); if (live_backend) *live_backend = (long)g_fake_regs.size(); }
-    if (violations) *violations = g_fake_violations.load();
-    if (backend_calls) *backend_calls = g_fake_calls.load();
-    return GOMEL_OK;
-}
-// The per-call pin scope (PinnedScope: want / commit / release at scope exit) on caller buffers, as gomel_from_mel_batch uses it --
-// without the copies: lets threads hammer the registry with aliased and nested ranges.
-int gomel_debug_pin_scope(void* const* ptrs, const size_t* bytes, size_t n, int hold_us) {
-    GOMEL_TRY
-    PinnedScope pins;
-    for (size_t i = 0; i < n; i++) pins.want(ptrs[i], bytes[i]);
-    pins.commit();
-    if (hold_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(hold_us));
-    return (int)pins.held.size();
-    GOMEL_CATCH
-}
-// The device-buffer cache against host malloc: random allocate / release / trim sequences with its invariants checked
-// (`cached` = the bytes of the unused blocks; a released block is handed out again or freed exactly once; clear() leaves nothing).
-// Returns the number of violated invariants.
-static thread_local long g_selftest_live = 0;   // (per thread: several self-tests may run at once)
-int gomel_debug_pool_selftest(unsigned seed, int iters) {
-    GOMEL_TRY
-    DevPool pool;
-    pool.alloc_fn = [](void** q, size_t n) { *q = malloc(n); if (*q) g_selftest_live++; return *q ? hipSuccess : hipErrorOutOfMemory; };
-    pool.free_fn = [](void* q) { free(q); g_selftest_live--; return hipSuccess; };
-    pool.cap = (size_t)8 << 20;
-    const long live0 = g_selftest_live;
-    std::vector<std::pair<void*, size_t>> held;
-    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
-    auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-    int bad = 0;
-    for (int i = 0; i < iters; i++) {
-        const uint64_t r = rnd();
-        if (held.size() < 24 && (r & 3) != 0) {
-            void* p = nullptr;
-            const size_t n = (size_t)1 << (8 + r % 13);
-            if (pool.alloc(&p, n + (r >> 20) % 4096) != hipSuccess || !p) { bad++; continue; }
-            memset(p, 0xa5, 64);                                    // the block is really ours (ASan would object otherwise)
-            for (auto& h : held) if (h.first == p) bad++;            // handed out twice
-            held.emplace_back(p, n);
-        } else if (!held.empty()) {
-            const size_t k = r % held.size();
-            pool.release(held[k].first);
-            held.erase(held.begin() + k);
-        }
-        size_t unused = 0;
-        for (const DevPool::Block& b : pool.blocks) if (!b.used) unused += b.bytes;
-        if (unused != pool.cached || pool.cached > pool.cap) bad++;
-        if ((r & 1023) == 0) { pool.trim(0); if (pool.cached != 0) bad++; }
-    }
-    for (auto& h : held) pool.release(h.first);
-    pool.clear();
-    if (g_selftest_live != live0) bad++;
-    return bad;
-    GOMEL_CATCH
-}
 #ifdef GOMEL_STAMPS   // diagnostic build only: read (and clear) the per-phase cycle sums of k_gl_fused
 int gomel_debug_stamps(unsigned long long* out21, int clear) {
     if (out21 && hipMemcpyFromSymbol(out21, HIP_SYMBOL(g_stamp_acc), 21 * sizeof(unsigned long long)) != hipSuccess) return GOMEL_ERR_HIP;
@@ -2647,27 +2045,6 @@ int gomel_debug_stamps(unsigned long long* out21, int clear) {
 #endif
 
 // ---- host memory helpers: pinned buffers a bulk caller reuses across calls (no per-call hipHostRegister)
-int gomel_plan_chunks_mode(const gomel_config* cfg, int32_t fp64_iterations, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks) {
-    if (!cfg || !n_pairs || !bounds || !n_chunks) return GOMEL_ERR_NULL;
-    if (n_utt == 0) return GOMEL_ERR_EMPTY;
-    if (cfg->num_mels <= 0 || cfg->window <= 0 || cfg->resolut < 4) return GOMEL_ERR_BAD_CONFIG;
-    for (size_t u = 0; u < n_utt; u++) {
-        if (n_pairs[u] == 0) return GOMEL_ERR_EMPTY;
-        if (n_pairs[u] % (size_t)cfg->num_mels) return GOMEL_ERR_BAD_LENGTH;
-    }
-    GOMEL_TRY
-    if (fp64_iterations == GOMEL_SCHEDULE_AUTO) fp64_iterations = gomel_auto_fp64_iterations(cfg, cfg->griffin_lim_iterations);
-    const std::vector<size_t> b = plan_chunks(*cfg, n_utt, n_pairs, fp64_iterations != 0 || !gomel_supported_n(cfg->resolut));
-    if (b.size() > cap) return GOMEL_ERR_BUFFER_TOO_SMALL;
-    for (size_t i = 0; i < b.size(); i++) bounds[i] = b[i];
-    *n_chunks = b.size() - 1;
-    return GOMEL_OK;
-    GOMEL_CATCH
-}
-int gomel_plan_chunks(const gomel_config* cfg, size_t n_utt, const size_t* n_pairs, size_t* bounds, size_t cap, size_t* n_chunks) {
-    return gomel_plan_chunks_mode(cfg, GOMEL_SCHEDULE_AUTO, n_utt, n_pairs, bounds, cap, n_chunks);
-}
-
 void* gomel_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

@@ -1,5 +1,5 @@
 """Diagnostic: where an iteration's cycles go inside k_gl_persist.  Needs a -DGOMEL_STAMPS build:
-   hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DGOMEL_STAMPS -o abtest/lib_stamps.so gomel_amd/csrc/gomel_hip.hip
+   python3 -m gomel_amd.build --force -o abtest/lib_stamps.so -DGOMEL_STAMPS
 usage: stamp_persist.py abtest/lib_stamps.so"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """Diagnostic: where a frame's cycles go inside k_gl_fused.  Needs a -DGOMEL_STAMPS build of the library:
-   hipcc -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -DGOMEL_STAMPS -o abtest/lib_stamps.so gomel_amd/csrc/gomel_hip.hip
+   python3 -m gomel_amd.build --force -o abtest/lib_stamps.so -DGOMEL_STAMPS
 usage: stamp_probe.py abtest/lib_stamps.so [T|D|S]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

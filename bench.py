@@ -565,6 +565,11 @@ def main():
         tkey = {"k_gl_fused_d": "fused_d", "k_gl_fused": "fused", "k_gl_fused_any": "fused", "k_gl_persist": "persistent", "k_gl_frames": "generic"}.get(dom, dom)
         traffic, traffic_source = committed_traffic(wl if wl != "cfg5" else "cfg3", tkey)
         per_frame_bytes = I * algorithmic_bytes_per_frame_iter(N, hop) + K * 16 + hop * 8
+        # the CALL, not only its dominant kernel: the same bytes over the launch-weighted mean of the iteration kernels (35 fp64 + 25 fp32
+        # launches of the default call at config 3) -- the fraction a Griffin-Lim iteration of this call runs at, whichever kernel carries it
+        n_launches = sum(kv["launches_per_call"] for kv in kernels.values())
+        mean_launch = sum(kv["launch_ms"] * kv["launches_per_call"] for kv in kernels.values()) / max(1, n_launches) * 1e-3
+        eff_frac = bytes_launch / mean_launch / 1e9 / HBM_PEAK_GBS if mean_launch > 0 else None
         line = {
             "metric": "Griffin-Lim frames/s (4096-pt, 60 iters)" if N == 4096 else "Griffin-Lim frames/s (%d-pt, %d iters)" % (N, I),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -583,6 +588,7 @@ def main():
             "pageable_frames_per_s": pageable,
             "float32_host_io_frames_per_s": f32io,   # gomel_from_mel_batch_f32: float log-mel in, float waveforms out (half the PCIe bytes); informational
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "effective_frac_per_iteration": eff_frac, "mean_launch_ms_per_iteration": mean_launch * 1e3,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launch_ms": t_launch * 1e3,
                          "launch_ms_per_timed_call": tm.get("per_call_launch_ms"),
                          "algorithmic_bytes_per_launch": bytes_launch,

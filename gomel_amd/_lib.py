@@ -98,6 +98,8 @@ SYMBOLS = {
     "gomel_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "gomel_last_hip_error": (ctypes.c_int, []),
     "gomel_abi_version": (ctypes.c_int, []),
+    "gomel_numa_cpus": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_size_t, c_size_p]),
+    "gomel_numa_bind_thread": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "gomel_device_count": (ctypes.c_int, []),
     "gomel_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
 }

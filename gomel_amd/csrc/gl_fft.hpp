@@ -68,8 +68,6 @@ template <class V> struct Twiddles {
     const V* w2r = nullptr;  // optional: THIS lane's 16 pass-2 twiddles (index u*R2 + q) already in registers -- they depend on
                              // the lane only, so a kernel that walks many frames loads them once (k_gl_fused) instead of 30 LDS
                              // reads per frame (forward + inverse)
-    const V* wn_src = nullptr;   // optional (fp64 fused kernel, GL_D_WN_EARLY): this lane's eight spectral-step W_N^k, table [8][T] in LDS, are fetched
-    V* wn_dst = nullptr;         // into wn_dst[0..7] in front of pass 3's reads, so that they land under the last butterfly instead of behind it
 };
 
 // ---------------------------------------------------------------------------------------------- complex helpers
@@ -330,10 +328,15 @@ template <int NV, int NW> GL_DEV void sgb_valu_then_write() {   // NW times: NV 
 // ---------------------------------------------------------------------------------------------- forward
 // In: v[j] = z[t + T*j].  Out: v[0..7] = Z[bA + B3*r], v[8..15] = Z[bB + B3*r] with bA = t, bB = (t ? B3 - t : B3/2).
 // `lds` is this stream's exchange area (G::LDS_SLOTS slots).  SYNC() is a barrier covering the stream's lanes.
-// PAIRED: the caller runs fft_inverse on the same exchange area right after the spectral step.  Pass 3 reads, and the inverse's first
-// pass writes, the SAME slots from the SAME lane (r * SB + bA, r * SB + bB: every slot of layout B belongs to exactly one lane there),
-// so the "reads done -> may write" synchronisation between the two is not needed: one barrier (or one event pair) less per frame.
-template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
+// PAIRED (bit 0): the caller runs fft_inverse on the same exchange area right after the spectral step.  Pass 3 reads, and the inverse's
+// first pass writes, the SAME slots from the SAME lane (r * SB + bA, r * SB + bB: every slot of layout B belongs to exactly one lane
+// there), so the "reads done -> may write" synchronisation between the two is not needed: one barrier (or one event pair) less per frame.
+// PAIRED bit 1: ... and the next thing to touch the area after that fft_inverse is this function again (the fused kernels' frame loop).
+// Then layout A uses ONE row stride in both directions (SAI: the inverse's transposed write stays conflict-free, the forward's transposed
+// read takes a two-way conflict on one lane pair per group), the inverse's last reads and the next forward's first writes are again
+// same-lane-same-slot, and the synchronisation between THEM goes too.
+template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
+    constexpr int SA = (PAIRED & 2) ? G::SAI : G::SA;
     // ---- pass 1: NB1 radix-R1 butterflies; butterfly u holds registers j = u + NB1*m, t1 = t + T*u
     // The pass's twiddles are read into registers BEFORE any exchange store: table and exchange area live in the same
     // LDS array, so a twiddle read placed after a store could not be hoisted above it (one LDS round trip per element).
@@ -348,14 +351,14 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
     constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
     if constexpr (ILV) {
         st.mark(0);
-        sync_before_write(sync);
+        if constexpr (!(PAIRED & 2)) sync_before_write(sync);
 #pragma unroll
         for (int u = 0; u < G::NB1; u++) {
             const int t1 = t + G::T * u;
 #pragma unroll
             for (int q = 0; q < G::R1; q++) {
                 if (q) v[u + G::NB1 * q] = cmul(v[u + G::NB1 * q], w1[u + G::NB1 * q]);
-                lds[q * G::SA + t1] = v[u + G::NB1 * q];
+                lds[q * SA + t1] = v[u + G::NB1 * q];
             }
         }
         sgb_valu_then_write<4, 16>();
@@ -363,12 +366,12 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) apply_tw<false, G::NB1, G::R1>(&v[u], &w1[u]);
     st.mark(0);
-    sync_before_write(sync);
+    if constexpr (!(PAIRED & 2)) sync_before_write(sync);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
 #pragma unroll
-        for (int q = 0; q < G::R1; q++) lds[q * G::SA + t1] = v[u + G::NB1 * q];
+        for (int q = 0; q < G::R1; q++) lds[q * SA + t1] = v[u + G::NB1 * q];
     }
     }
     sync();
@@ -378,7 +381,7 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
 #pragma unroll
-        for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * G::SA + t2 + 8 * m];
+        for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * SA + t2 + 8 * m];
     }
     sync_reads_done(sync);
     st.mark(2);
@@ -421,13 +424,9 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
     st.mark(4);
     // ---- pass 3: the mirrored radix-8 butterflies bA, bB
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
-    if (tw.wn_dst) {
-#pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) tw.wn_dst[s8] = tw.wn_src[s8 * G::T + t];
-    }
 #pragma unroll
     for (int r = 0; r < 8; r++) { v[r] = lds[r * G::SB + bA]; v[8 + r] = lds[r * G::SB + bB]; }
-    if constexpr (!PAIRED) sync_reads_done(sync);
+    if constexpr (!(PAIRED & 1)) sync_reads_done(sync);
     st.mark(5);
     dft8<false, 1>(&v[0]);
     dft8<false, 1>(&v[8]);
@@ -439,11 +438,11 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
 // (unnormalised; the 1/N of fft.IFFT is folded into the target magnitudes).
 // `w1_out` (optional): receives this lane's pass-1 twiddles as they are read (index u + NB1*q, the layout of Twiddles::w1r), so that a
 // kernel whose next step is a forward FFT can hand them to it instead of reading the table again.
-template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st, V* w1_out = nullptr) {
+template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st, V* w1_out = nullptr) {
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
     constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
     if constexpr (ILV) {   // the first butterfly's eight outputs leave while the second one computes
-        if constexpr (!PAIRED) sync_before_write(sync);
+        if constexpr (!(PAIRED & 1)) sync_before_write(sync);
         dft8<true, 1>(&v[0]);
 #pragma unroll
         for (int r = 0; r < 8; r++) lds[r * G::SB + bA] = v[r];
@@ -457,7 +456,7 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
     dft8<true, 1>(&v[0]);
     dft8<true, 1>(&v[8]);
     st.mark(8);
-    if constexpr (!PAIRED) sync_before_write(sync);
+    if constexpr (!(PAIRED & 1)) sync_before_write(sync);
 #pragma unroll
     for (int r = 0; r < 8; r++) { lds[r * G::SB + bA] = v[r]; lds[r * G::SB + bB] = v[8 + r]; }
     }
@@ -498,7 +497,7 @@ template <class G, bool PAIRED = false, class V, class SyncT, class St> GL_DEV v
         }
         apply_tw<true, G::NB1, G::R1>(&v[u], w1);
     }
-    sync_reads_done(sync);
+    if constexpr (!(PAIRED & 2)) sync_reads_done(sync);
     st.mark(12);
 #pragma unroll
     for (int u = 0; u < G::NB1; u++) dftR<true, G::R1, G::NB1>(&v[u]);
@@ -789,48 +788,12 @@ GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     v2d t = e - io;
     b = v2d{t.x, -t.y};
 }
-// The same in two sweeps with ONE range test per frame (GL_D_ONEBALLOT): sweep 1 leaves 2 X[k] / 2 conj(X[C-k]) in place of Z[k] / Z[C-k]
-// and folds the sixteen squared moduli into a per-lane minimum and maximum; one ballot; sweep 2 scales by the unit phasors (fast or
-// scaled form for the whole frame) and merges.  Eight compare pairs and seven branches fewer than clamp_pair_d's test per pair.
-#ifndef GL_D_ONEBALLOT
-#define GL_D_ONEBALLOT 0
-#endif
-template <class G> GL_DEV void spectral_apply_oneballot(v2d (&v)[16], const MagRegsD& m, const v2d (&w)[8]) {
-    double lo = 1e300, hi = 0.0;
-    double pk[8], pc[8];
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        v2d &a = v[s], &b = v[15 - s];
-        const v2d bc = v2d{b.x, -b.y};
-        const v2d p = a + bc, d = a - bc;
-        const v2d q = cmul(w[s], rot_mi(d));
-        a = p + q; b = p - q;
-        pk[s] = __builtin_fma(a.x, a.x, a.y * a.y); pc[s] = __builtin_fma(b.x, b.x, b.y * b.y);
-        lo = fmin(lo, fmin(pk[s], pc[s])); hi = fmax(hi, fmax(pk[s], pc[s]));
-    }
-    const bool rare = __builtin_expect(__builtin_amdgcn_ballot_w64(!(lo > 1e-280) || !(hi < 1e280)) != 0, 0);
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        v2d &a = v[s], &b = v[15 - s];
-        v2d u, vv;
-        if (rare) { u = unit_phase_d(a) * m.ma[s]; vv = unit_phase_d(b) * m.mb[s]; }
-        else { u = a * (half_rsqrt_d(pk[s]) * (m.ma[s] + m.ma[s])); vv = b * (half_rsqrt_d(pc[s]) * (m.mb[s] + m.mb[s])); }
-        const v2d e = u + vv, o = cmulc(u - vv, w[s]), io = rot_pi(o);
-        a = e + io;
-        const v2d tt = e - io;
-        b = v2d{tt.x, -tt.y};
-    }
-}
 template <class G> GL_DEV void spectral_apply(v2d (&v)[16], int t, const MagRegsD& m, const v2d (&w)[8]) {
     const bool is0 = (t == 0);
     v2d dc = v[0];
     lane0_permute<G>(v, is0);
-#if GL_D_ONEBALLOT
-    spectral_apply_oneballot<G>(v, m, w);
-#else
 #pragma unroll
     for (int s = 0; s < 8; s++) clamp_pair_d(v[s], v[15 - s], w[s], m.ma[s], m.mb[s]);
-#endif
     if (is0) {
         const double x0 = dc.x + dc.y, xn = dc.x - dc.y;
         const double y0 = x0 < 0.0 ? -m.m0 : m.m0, yn = xn < 0.0 ? -m.mn : m.mn;

@@ -410,27 +410,23 @@ template <bool WIDE> struct StreamFlagSync {
     }
     GL_DEV void wait() {
         if constexpr (WIDE) {
-#ifndef GL_ABL_NOPOLL   // (timing ablation, results garbage: what the polling itself costs)
             asm volatile("" ::: "memory");
             while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {}
             asm volatile("" ::: "memory");
-#endif
         }
     }
     GL_DEV void operator()() { arrive(); wait(); }
 };
 
+// The fused kernels' forward / inverse FFT as a pair (gl_fft.hpp, PAIRED): bit 0 = no synchronisation between forward pass 3's reads and
+// the inverse's first writes (same lane, same slots); bit 1 = nor between the inverse's last reads and the next frame's first writes (one row
+// stride for layout A in both directions).  Bit-identical results; k_gl_fused_d -0.7 ... -0.8 % with 3 on two boxes, k_gl_fused -0.4 ... -0.7 %
+// with 1 and +0.4 % with 3 (profiles/r05/ab_fp64_round5_knobs.txt).
 #ifndef GL_PAIRED
-#define GL_PAIRED 0   // the fused kernels' forward / inverse FFT as a pair: no synchronisation between pass 3's reads and the inverse's first writes (gl_fft.hpp)
+#define GL_PAIRED 1
 #endif
-#ifndef GL_D_WN_EARLY
-#define GL_D_WN_EARLY 0
-#endif
-#ifndef GL_D_MAGS_EARLY
-#define GL_D_MAGS_EARLY 0
-#endif
-#ifndef GL_D_NYQ_ONCE
-#define GL_D_NYQ_ONCE 0
+#ifndef GL_D_PAIRED
+#define GL_D_PAIRED 3
 #endif
 #ifndef GL_WIN_B128
 #define GL_WIN_B128 0
@@ -1456,7 +1452,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     v2d* tw2_l = tw1_l + G::TW1_N;
     v2d* win_l = tw2_l + G::TW2_N;
     constexpr bool WN_LDS = GL_D_WN_LDS && N >= GL_D_WN_LDS_MINN;
-    constexpr bool WN_EARLY = GL_D_WN_EARLY && WN_LDS;
     v2d* wn_l = win_l + G::C;                                  // [8][T] (WN_LDS only)
     int* g_sh = reinterpret_cast<int*>(wn_l + (WN_LDS ? 8 * T : 0));
     unsigned* cnt_sh = reinterpret_cast<unsigned*>(g_sh + STREAMS);   // [STREAMS][2]: one event counter per wave of a two-wave stream (N 4096)
@@ -1544,35 +1539,12 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
 #else
     NoStamps st;
 #endif
-#if GL_D_MAGS_EARLY
-    MagRawD mnext;
-    load_mag_rows_d<G>(mnext, t, mag_p);
-    mnext.nq = nyq_p[0];
-#endif
-    // Nyquist magnitudes of all the segment's frames: ONE vector load per wave (lane = frame, G <= kMaxSegFrames = 64) and two v_readlane
-    // per frame, as k_gl_fused does.  The per-frame scalar load it replaces returned out of order with the LDS reads, so the first
-    // counted LDS wait behind it -- at the frame's head, in front of the window reads -- became lgkmcnt(0) and sat out the scalar load's latency.
-    constexpr bool NYQ_ONCE = GL_D_NYQ_ONCE && T >= 64;
-    double nyq_all = 0.0;
-    if constexpr (NYQ_ONCE) {
-        const int l = threadIdx.x & 63;
-        nyq_all = nyq_p[l < d.G ? l : 0];
-        asm volatile("v_mov_b64 %0, %0" : "+v"(nyq_all));   // consume the load here: no vmcnt wait in front of every frame's v_readlane
-    }
     for (int g = 0; g < g_max; g++) {
         const bool active = live && g < d.G;
         const int gg = g < d.G ? g : d.G - 1;
-#if GL_D_MAGS_EARLY
-        MagRawD mraw = mnext;                                                 // requested at the start of the previous frame's inverse FFT
-#else
         MagRawD mraw;                                                         // issued now, finished after the forward FFT
         load_mag_rows_d<G>(mraw, t, mag_p + (int64_t)gg * G::C);
-        if constexpr (NYQ_ONCE) {
-            const unsigned long long bits = __builtin_bit_cast(unsigned long long, nyq_all);
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)bits, gg), hi = __builtin_amdgcn_readlane((unsigned)(bits >> 32), gg);
-            mraw.nq = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-        } else mraw.nq = nyq_p[gg];
-#endif
+        mraw.nq = nyq_p[gg];
         st.mark(16);
         // (k_gl_fused's single window read per frame was tried here too: 64 more live registers around the back edge, 3 % MORE
         // vector instructions through the AGPR traffic they cause -- the window is read twice)
@@ -1598,30 +1570,22 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
         }
         st.mark(15);   // (window reads + multiply, slide, next rows' loads issued)
         if constexpr (W1CARRY) {
-            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr, WN_EARLY ? wn_l : nullptr, WN_EARLY ? wn : nullptr};
-            fft_forward<G, GL_PAIRED>(v, my, t, twf, sync, st);
+            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr};
+            fft_forward<G, GL_D_PAIRED>(v, my, t, twf, sync, st);
         } else {
-            const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, nullptr, 0, nullptr, WN_EARLY ? wn_l : nullptr, WN_EARLY ? wn : nullptr};
-            fft_forward<G, GL_PAIRED>(v, my, t, twf, sync, st);
+            fft_forward<G, GL_D_PAIRED>(v, my, t, tw, sync, st);
         }
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
-            if constexpr (WN_LDS && !WN_EARLY) {
+            if constexpr (WN_LDS) {
 #pragma unroll
                 for (int s8 = 0; s8 < 8; s8++) wn[s8] = wn_l[s8 * T + t];
             }
             spectral_apply<G>(v, t, mr, wn);
         }
-#if GL_D_MAGS_EARLY
-        {   // the next frame's magnitude row and Nyquist scalar: the inverse FFT covers their latency, the frame's head carries five loads less
-            const int gn = g + 1 < d.G ? g + 1 : d.G - 1;
-            load_mag_rows_d<G>(mnext, t, mag_p + (int64_t)gn * G::C);
-            mnext.nq = nyq_p[gn];
-        }
-#endif
         st.mark(7);
-        fft_inverse<G, GL_PAIRED>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
+        fft_inverse<G, GL_D_PAIRED>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] = xl[jj];
         if (any_next) {

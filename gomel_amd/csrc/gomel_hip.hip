@@ -1698,6 +1698,16 @@ static int from_mel_batch_guarded(gomel_handle* h, size_t n_utt, const void* con
 // One call, several GPUs: contiguous utterance shards balanced by frame count, one host thread per handle (a handle = one
 // device), no data-path collective.  What a Go host uses to drive the 8 GPUs of a node without Python; every
 // handle must have been created from the same configuration (use gomel_create_from_tables for bit-identical tables).
+// The calling host thread onto the CPUs of the NUMA node `device` hangs off (a fresh per-shard thread of gomel_from_mel_batch_multi;
+// one process drives several GPUs there, so a process-wide binding as the Python ranks do it would be wrong).  No NUMA information,
+// GOMEL_NUMA_BIND=0, or a node outside the thread's mask: the thread stays where it is.  GOMEL_SYSFS_ROOT: another sysfs tree (tests).
+static void bind_thread_to_device_node(int device) {
+    static const bool enabled = [] { const char* e = getenv("GOMEL_NUMA_BIND"); return !(e && *e == '0'); }();
+    if (!enabled) return;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)gomel_numa_bind_thread(getenv("GOMEL_SYSFS_ROOT"), bdf, nullptr, nullptr);
+}
 static int from_mel_batch_multi_guarded(gomel_handle* const* hs, size_t n_handles, size_t n_utt, const void* const* mel, const size_t* n_pairs,
                                         const void* const* x0, const uint64_t* seeds, void* const* out, const size_t* out_cap, int io32) {
     if (!hs || !mel || !n_pairs || !out) return GOMEL_ERR_NULL;
@@ -1732,6 +1742,7 @@ static int from_mel_batch_multi_guarded(gomel_handle* const* hs, size_t n_handle
         if (hi <= lo) continue;
         th.emplace_back([&, r, lo, hi] {
             try {
+                bind_thread_to_device_node(hs[r]->device);   // this shard's pinning and copy submission run beside its GPU's root port
                 rcs[r] = from_mel_batch_guarded(hs[r], hi - lo, mel + lo, n_pairs + lo, x0 ? x0 + lo : nullptr, seeds + lo, out + lo, out_cap ? out_cap + lo : nullptr, io32);
             } catch (...) { rcs[r] = GOMEL_ERR_NO_MEMORY; }
         });
@@ -2055,34 +2066,6 @@ int gomel_host_free(void* p) {
     HIPCHK(hipHostFree(p));
     return GOMEL_OK;
 }
-// The caller's pointer -> the registration that covers it.  acquire() hands back the BASE of an enclosing live registration when the
-// range lies inside one (a per-call pin of another thread, an earlier larger register), so the pointer itself is not the token.
-static std::mutex g_reg_mu;
-static std::multimap<uintptr_t, uintptr_t> g_reg_tokens;
-int gomel_host_register(void* p, size_t bytes) {   // keeps the range pinned until gomel_host_unregister (reference-counted with the per-call pins)
-    if (!p || bytes == 0) return GOMEL_ERR_NULL;
-    GOMEL_TRY
-    const uintptr_t tok = g_pins.acquire(p, bytes);
-    if (!tok) return GOMEL_ERR_HIP;
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    g_reg_tokens.emplace((uintptr_t)p, tok);
-    return GOMEL_OK;
-    GOMEL_CATCH
-}
-int gomel_host_unregister(void* p) {
-    if (!p) return GOMEL_ERR_NULL;
-    uintptr_t tok = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_reg_mu);
-        auto it = g_reg_tokens.find((uintptr_t)p);
-        if (it == g_reg_tokens.end()) return GOMEL_ERR_BAD_CONFIG;   // not a pointer gomel_host_register took
-        tok = it->second;
-        g_reg_tokens.erase(it);
-    }
-    g_pins.release(tok);
-    return GOMEL_OK;
-}
-
 // ---- exception firewall: the entry points that allocate on the host
 int gomel_set_window(gomel_handle* h, const double* w, size_t n) {
     GOMEL_TRY return set_window_guarded(h, w, n); GOMEL_CATCH

@@ -3,6 +3,9 @@
 // with g++ into libgomel_hip.so beside gomel_hip.hip, and alone (libgomel_host.so) by scripts/sanitize_host.sh.
 #include "gomel_host.hpp"
 
+#include <pthread.h>
+#include <sched.h>
+
 extern "C" {
 
 int gomel_abi_version(void) { return GOMEL_HIP_ABI_VERSION; }
@@ -216,6 +219,66 @@ int gomel_debug_pool_selftest(unsigned seed, int iters) {
     pool.clear();
     if (g_selftest_live != live0) bad++;
     return bad;
+    GOMEL_CATCH
+}
+
+// The caller's pointer -> the registration that covers it.  acquire() hands back the BASE of an enclosing live registration when the
+// range lies inside one (a per-call pin of another thread, an earlier larger register), so the pointer itself is not the token.
+static std::mutex g_reg_mu;
+static std::multimap<uintptr_t, uintptr_t> g_reg_tokens;
+int gomel_host_register(void* p, size_t bytes) {   // keeps the range pinned until gomel_host_unregister (reference-counted with the per-call pins)
+    if (!p || bytes == 0) return GOMEL_ERR_NULL;
+    GOMEL_TRY
+    const uintptr_t tok = g_pins.acquire(p, bytes);
+    if (!tok) return GOMEL_ERR_HIP;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_reg_tokens.emplace((uintptr_t)p, tok);
+    return GOMEL_OK;
+    GOMEL_CATCH
+}
+int gomel_host_unregister(void* p) {
+    if (!p) return GOMEL_ERR_NULL;
+    uintptr_t tok = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_reg_tokens.find((uintptr_t)p);
+        if (it == g_reg_tokens.end()) return GOMEL_ERR_BAD_CONFIG;   // not a pointer gomel_host_register took
+        tok = it->second;
+        g_reg_tokens.erase(it);
+    }
+    g_pins.release(tok);
+    return GOMEL_OK;
+}
+
+int gomel_numa_cpus(const char* sysfs_root, const char* pci_bus_id, int32_t* node, int32_t* cpus, size_t cap, size_t* n_cpus) {
+    GOMEL_TRY
+    std::vector<int> v;
+    int nd = -1;
+    const int rc = numa_cpus_of(sysfs_root, pci_bus_id, &nd, v);
+    if (node) *node = nd;
+    if (n_cpus) *n_cpus = rc == GOMEL_OK ? v.size() : 0;
+    if (rc) return rc;
+    if (cpus) for (size_t i = 0; i < v.size() && i < cap; i++) cpus[i] = v[i];
+    return GOMEL_OK;
+    GOMEL_CATCH
+}
+int gomel_numa_bind_thread(const char* sysfs_root, const char* pci_bus_id, int32_t* node, int32_t* n_bound) {
+    GOMEL_TRY
+    if (n_bound) *n_bound = 0;
+    std::vector<int> v;
+    int nd = -1;
+    const int rc = numa_cpus_of(sysfs_root, pci_bus_id, &nd, v);
+    if (node) *node = nd;
+    if (rc) return rc;
+    cpu_set_t have, want;
+    CPU_ZERO(&have); CPU_ZERO(&want);
+    if (pthread_getaffinity_np(pthread_self(), sizeof have, &have) != 0) return GOMEL_ERR_EMPTY;
+    int n = 0;
+    for (int c : v) if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &have)) { CPU_SET(c, &want); n++; }
+    if (n == 0) return GOMEL_ERR_EMPTY;                                         // the node's CPUs lie outside this thread's mask (cgroup, taskset): leave it alone
+    if (pthread_setaffinity_np(pthread_self(), sizeof want, &want) != 0) return GOMEL_ERR_EMPTY;
+    if (n_bound) *n_bound = n;
+    return GOMEL_OK;
     GOMEL_CATCH
 }
 

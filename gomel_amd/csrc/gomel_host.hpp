@@ -481,3 +481,48 @@ template <class EvOps> struct DeviceGateT {
         v.push_back(Ent{ev, owner});
     }
 };
+
+// ----------------------------------------------------------------------------------------------- NUMA locality of host threads
+// The CPUs of the NUMA node a PCI device hangs off, from sysfs (root injectable: the CPU tests run on a fake tree).  Used by the
+// one-process multi-GPU path (gomel_from_mel_batch_multi: one host thread per device) the way gomel_amd.dist.bind_to_gpu_numa_node
+// binds the one-process-per-GPU ranks.
+static bool read_small_file(const std::string& path, std::string& out) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    out.assign(buf, n);
+    return true;
+}
+static bool parse_cpulist(const std::string& s, std::vector<int>& cpus) {   // "0-3,16-19\n" -> 0 1 2 3 16 17 18 19
+    cpus.clear();
+    size_t i = 0;
+    auto num = [&](long& v) {
+        if (i >= s.size() || s[i] < '0' || s[i] > '9') return false;
+        v = 0;
+        while (i < s.size() && s[i] >= '0' && s[i] <= '9') { v = v * 10 + (s[i] - '0'); if (v > (1 << 20)) return false; i++; }
+        return true;
+    };
+    while (i < s.size() && s[i] != '\n' && s[i] != '\0') {
+        long a, b;
+        if (!num(a)) return false;
+        b = a;
+        if (i < s.size() && s[i] == '-') { i++; if (!num(b) || b < a) return false; }
+        for (long c = a; c <= b; c++) cpus.push_back((int)c);
+        if (i < s.size() && s[i] == ',') i++;
+    }
+    return !cpus.empty();
+}
+static int numa_cpus_of(const char* sysfs_root, const char* bdf, int* node_out, std::vector<int>& cpus) {
+    if (!bdf || !*bdf) return GOMEL_ERR_NULL;
+    std::string root = sysfs_root && *sysfs_root ? sysfs_root : "/sys", id = bdf, txt;
+    for (char& c : id) if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');   // sysfs spells bus ids in lower case
+    if (!read_small_file(root + "/bus/pci/devices/" + id + "/numa_node", txt)) return GOMEL_ERR_EMPTY;
+    const long node = strtol(txt.c_str(), nullptr, 10);
+    if (node_out) *node_out = (int)node;
+    if (node < 0) return GOMEL_ERR_EMPTY;                                       // single-node machine, or not reported
+    if (!read_small_file(root + "/devices/system/node/node" + std::to_string(node) + "/cpulist", txt) || !parse_cpulist(txt, cpus)) return GOMEL_ERR_EMPTY;
+    return GOMEL_OK;
+}
+

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOMEL_HIP_ABI_VERSION 4
+#define GOMEL_HIP_ABI_VERSION 5
 
 typedef enum gomel_status {
     GOMEL_OK = 0,
@@ -175,7 +175,9 @@ int gomel_set_call_mode(gomel_handle* h, int mode);
 /* One call, several GPUs of one node (SURVEY 8e "one host thread/stream per device"): `handles` holds one handle per device,
  * all created from the same configuration (gomel_create_from_tables gives them bit-identical tables); the utterances are cut
  * into contiguous shards balanced by frame count, each shard runs gomel_from_mel_batch on its handle from its own host thread.
- * No collective on the data path; default seeds are the GLOBAL utterance indices, so results do not depend on the sharding. */
+ * No collective on the data path; default seeds are the GLOBAL utterance indices, so results do not depend on the sharding.
+ * Each shard's host thread first binds itself to the CPUs of the NUMA node its device hangs off (gomel_numa_bind_thread with the
+ * device's PCI bus id; GOMEL_NUMA_BIND=0 switches that off), so that its pinning and copy submission run beside the GPU's root port. */
 int gomel_from_mel_batch_multi(gomel_handle* const* handles, size_t n_handles, size_t n_utt, const double* const* mel_pairs,
                                const size_t* n_pairs, const double* const* x0, const uint64_t* seeds, double* const* out,
                                const size_t* out_cap);
@@ -290,6 +292,16 @@ int gomel_target_magnitudes(gomel_handle* h, const double* mel_pairs, size_t n_p
 const char* gomel_strerror(int status);
 int gomel_last_hip_error(void);
 int gomel_abi_version(void);
+
+/* NUMA locality of host threads (host-side PCIe traffic, not xGMI, limits the 8-GPU case).  Host logic only.
+ *   gomel_numa_cpus: the NUMA node of the PCI device `pci_bus_id` ("0000:85:00.0", from hipDeviceGetPCIBusId) and that node's CPUs,
+ *     read from <sysfs_root>/bus/pci/devices/<bdf>/numa_node and <sysfs_root>/devices/system/node/node<N>/cpulist (sysfs_root NULL
+ *     = "/sys"; injectable for tests).  *n_cpus receives the count even when cap is smaller.  GOMEL_ERR_EMPTY when the machine does not
+ *     say (no such device, numa_node = -1, no cpulist): not an error for the caller, there is simply nothing to bind to.
+ *   gomel_numa_bind_thread: restricts the CALLING thread to those CPUs, intersected with its current affinity mask (never widens
+ *     it); *n_bound = CPUs it now runs on.  GOMEL_ERR_EMPTY as above, or when the intersection is empty (the thread is left alone). */
+int gomel_numa_cpus(const char* sysfs_root, const char* pci_bus_id, int32_t* node, int32_t* cpus, size_t cap, size_t* n_cpus);
+int gomel_numa_bind_thread(const char* sysfs_root, const char* pci_bus_id, int32_t* node, int32_t* n_bound);
 int gomel_device_count(void);
 int gomel_device_name(const gomel_handle* h, char* buf, size_t cap);
 

@@ -9,7 +9,10 @@
 //   * the table builder (gomel_tables_build: Hann, undomel / domel rows, mel/impl.go:311-322,348-359) on random configurations,
 //     every thread checking that the same configuration gives the same bytes;
 //   * the chunk planner (gomel_plan_chunks) and the automatic precision schedule on random inputs (bounds strictly increasing, ...);
-//   * the device-buffer cache against host malloc (gomel_debug_pool_selftest: allocate / release / trim invariants).
+//   * the device-buffer cache against host malloc (gomel_debug_pool_selftest: allocate / release / trim invariants);
+//   * the device gate (DeviceGateT of gomel_host.hpp, instantiated here on FAKE events): threads enter / leave as ordinary and as
+//     persistent runs; a persistent run is never admitted while an ordinary one is enqueueing or in flight, the accounted share of the
+//     device never exceeds 1024/1024 and returns to zero.
 // Exit code 0 = no violation.  Diagnostic entry points are declared here by hand: they are not part of include/gomel_hip.h.
 #include <atomic>
 #include <cstdint>
@@ -20,6 +23,7 @@
 #include <vector>
 
 #include "gomel_hip.h"
+#include "../gomel_amd/csrc/gomel_host.hpp"   // header-only, device-free: the gate template is instantiated below on fake events
 
 extern "C" {
 int gomel_debug_pin_backend(int fake);
@@ -125,6 +129,63 @@ static void plan_worker(int id, int iters) {
     }
 }
 
+// ---- the device gate on fake events: an event is "ready" once its flag is set ------------------------------------------------------
+struct FakeEvent { std::atomic<int>* done; bool operator==(const FakeEvent& o) const { return done == o.done; } };
+struct FakeEvOps {
+    typedef FakeEvent Event;
+    static int query(FakeEvent e) { return e.done->load() ? 0 : 1; }
+};
+typedef DeviceGateT<FakeEvOps> FakeGate;
+static FakeGate g_fake_gate;
+static std::atomic<int> g_ordinary_in_flight{0};   // ordinary runs between enter and the completion of their event
+static void gate_worker(int id, int iters) {
+    Rng r(5000 + id);
+    std::vector<std::atomic<int>> flags(8);
+    for (auto& f : flags) f = 1;
+    int owner_tag = id;
+    for (int i = 0; i < iters; i++) {
+        std::atomic<int>& flag = flags[r.below(flags.size())];
+        if (r.below(3) != 0) {   // an ordinary run: enter (prune persistent launches), enqueue, record its event, complete a little later
+            {
+                std::lock_guard<std::mutex> lk(g_fake_gate.mu);
+                g_fake_gate.enqueueing++;
+                FakeGate::prune(g_fake_gate.ps);
+            }
+            g_ordinary_in_flight++;
+            flag = 0;
+            {
+                std::lock_guard<std::mutex> lk(g_fake_gate.mu);
+                g_fake_gate.enqueueing--;
+                FakeGate::put(g_fake_gate.np, FakeEvent{&flag}, &owner_tag);
+            }
+            if (r.below(2)) std::this_thread::yield();
+            g_ordinary_in_flight--;
+            flag = 1;             // (decrement first: an observer that still sees the event pending may see the count already lowered, never the reverse)
+        } else {                 // a persistent run: admitted only while nothing ordinary is enqueueing or in flight and the share fits
+            const int units = 128 + (int)r.below(900);
+            g_fake_gate.mu.lock();
+            FakeGate::prune(g_fake_gate.np);
+            bool others = g_fake_gate.enqueueing != 0;
+            for (const FakeGate::Ent& e : g_fake_gate.np) others |= e.owner != &owner_tag;
+            if (others || g_fake_gate.persist_units + units > 1024) { g_fake_gate.mu.unlock(); continue; }
+            g_fake_gate.persist_units += units;
+            CHECK(g_fake_gate.persist_units <= 1024);
+            flag = 0;
+            FakeGate::put(g_fake_gate.ps, FakeEvent{&flag}, &owner_tag);
+            g_fake_gate.mu.unlock();
+            if (r.below(2)) std::this_thread::yield();
+            flag = 1;
+            std::lock_guard<std::mutex> lk(g_fake_gate.mu);
+            g_fake_gate.persist_units -= units;
+            for (size_t k = 0; k < g_fake_gate.ps.size();) { if (g_fake_gate.ps[k].owner == &owner_tag) g_fake_gate.ps.erase(g_fake_gate.ps.begin() + k); else k++; }
+        }
+    }
+    // this worker's flags die with it: nothing of its may stay in the gate
+    std::lock_guard<std::mutex> lk(g_fake_gate.mu);
+    for (std::vector<FakeGate::Ent>* v : {&g_fake_gate.np, &g_fake_gate.ps})
+        for (size_t k = 0; k < v->size();) { if ((*v)[k].owner == &owner_tag) v->erase(v->begin() + k); else k++; }
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 300;
     for (char*& b : g_buf) { b = (char*)malloc(kBuf); if (!b) return 2; memset(b, 0, kBuf); }
@@ -135,6 +196,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; i++) th.emplace_back(plan_worker, i, iters);
     std::atomic<int> pool_bad{0};
     for (int i = 0; i < 2; i++) th.emplace_back([&pool_bad, i, iters] { pool_bad += gomel_debug_pool_selftest(11u + (unsigned)i, iters * 20); });
+    for (int i = 0; i < 4; i++) th.emplace_back(gate_worker, i, iters * 20);
     for (std::thread& t : th) t.join();
     long live_reg = -1, live_be = -1, viol = -1, calls = -1;
     gomel_debug_pin_stats(&live_reg, &live_be, &viol, &calls);
@@ -143,6 +205,7 @@ int main(int argc, char** argv) {
     CHECK(viol == 0);         // the registry never asked the runtime for an overlapping registration / an unknown unregistration
     CHECK(calls > 0);
     CHECK(pool_bad.load() == 0);
+    CHECK(g_fake_gate.persist_units == 0 && g_fake_gate.enqueueing == 0 && g_fake_gate.np.empty() && g_fake_gate.ps.empty());
     CHECK(gomel_debug_pin_backend(0) == GOMEL_OK);
     for (char* b : g_buf) free(b);
     printf("host_stress: %ld failures; pin backend calls %ld, violations %ld, live %ld/%ld; pool self-test violations %d\n", g_fail.load(), calls, viol, live_reg, live_be,

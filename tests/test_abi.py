@@ -45,7 +45,7 @@ def test_default_config_is_newmel(L):
     assert L.gomel_default_config(ctypes.byref(c)) == 0
     assert (c.num_mels, c.window, c.resolut, c.griffin_lim_iterations) == (160, 256, 2048, 2)     # mel/mel.go:30-41
     assert (c.mel_fmin, c.mel_fmax, c.tune_mul, c.tune_add) == (0.0, 8000.0, 1.0, 0.0)
-    assert L.gomel_abi_version() == 4
+    assert L.gomel_abi_version() == 5
 
 
 def test_length_helpers_match_oracle(L, oracle):

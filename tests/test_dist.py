@@ -126,3 +126,51 @@ def test_rank_binds_to_the_cpus_of_its_gpus_numa_node(tmp_path):
     assert not r["bound"] and "outside" in r["why"]
     assert gd.gpu_bus_ids(smi="/nonexistent/rocm-smi") == []
     assert gd._parse_cpulist("0-2,7,9-10\n") == {0, 1, 2, 7, 9, 10}
+
+
+def test_c_abi_numa_lookup_and_thread_binding_on_a_fake_sysfs(tmp_path):
+    """gomel_numa_cpus / gomel_numa_bind_thread (host logic, gomel_host.cpp): what gomel_from_mel_batch_multi's per-device threads use
+    -- the one-process multi-GPU path a Go host takes -- on a fake sysfs tree: node and CPU list of a PCI bus id (upper-case
+    ids as hipDeviceGetPCIBusId may spell them), the calling THREAD bound to that node's CPUs intersected with its mask (never widened),
+    GOMEL_ERR_EMPTY (4) where the machine does not say, the process's other threads untouched."""
+    import ctypes
+    import threading
+    from gomel_amd import _lib
+    L = _lib.lib()
+    allowed = sorted(os.sched_getaffinity(0))
+    sysfs = tmp_path / "sys"
+    mine = allowed[: max(1, len(allowed) // 2)]                      # a node made of CPUs this process may really use
+    lists = {0: ",".join(str(c) for c in mine), 1: "%d-%d" % (max(allowed) + 100, max(allowed) + 103)}
+    for bdf, node in (("0000:05:00.0", 0), ("0000:85:00.0", 1), ("0000:c5:00.0", -1)):
+        d = sysfs / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    for node, cpus in lists.items():
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    root = str(sysfs).encode()
+    node, n = ctypes.c_int32(-9), ctypes.c_size_t(0)
+    buf = (ctypes.c_int32 * 64)()
+    assert L.gomel_numa_cpus(root, b"0000:05:00.0", ctypes.byref(node), buf, 64, ctypes.byref(n)) == 0
+    assert node.value == 0 and list(buf[: n.value]) == mine
+    assert L.gomel_numa_cpus(root, b"0000:85:00.0", ctypes.byref(node), buf, 2, ctypes.byref(n)) == 0 and n.value == 4 and node.value == 1   # count beyond cap
+    assert list(buf[:2]) == [max(allowed) + 100, max(allowed) + 101]
+    assert L.gomel_numa_cpus(root, b"0000:C5:00.0", ctypes.byref(node), buf, 64, ctypes.byref(n)) == 4 and node.value == -1                 # numa_node = -1
+    assert L.gomel_numa_cpus(root, b"0000:ff:00.0", None, None, 0, None) == 4                                                                # no such device
+    assert L.gomel_numa_cpus(root, None, None, None, 0, None) == 7
+    res = {}
+
+    def worker():
+        nb, nd = ctypes.c_int32(0), ctypes.c_int32(-9)
+        res["rc"] = L.gomel_numa_bind_thread(root, b"0000:05:00.0", ctypes.byref(nd), ctypes.byref(nb))
+        res["node"], res["n"] = nd.value, nb.value
+        res["mask"] = sorted(os.sched_getaffinity(threading.get_native_id()))
+        res["rc_outside"] = L.gomel_numa_bind_thread(root, b"0000:85:00.0", None, ctypes.byref(nb))   # node 1's CPUs are not ours: left alone
+        res["mask_after"] = sorted(os.sched_getaffinity(threading.get_native_id()))
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert res["rc"] == 0 and res["node"] == 0 and res["n"] == len(mine) and res["mask"] == mine
+    assert res["rc_outside"] == 4 and res["mask_after"] == mine
+    assert sorted(os.sched_getaffinity(0)) == allowed                # the binding was the thread's, not the process's

@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
         if (rc != GOMEL_OK || !j1) FAIL(rc, "gomel_from_mel_batch_submit (1)");
         rc = gomel_from_mel_batch_submit(h, n_utt, mel_ptrs, lens, x0_ptrs, NULL, o2, NULL, &j2);
         if (rc != GOMEL_OK || !j2) FAIL(rc, "gomel_from_mel_batch_submit (2)");
-        if (gomel_destroy(h) != GOMEL_ERR_NULL) FAIL(GOMEL_ERR_NULL, "gomel_destroy with jobs outstanding must be refused");
+        if (gomel_destroy(h) != GOMEL_ERR_BUSY) FAIL(GOMEL_ERR_BUSY, "gomel_destroy with jobs outstanding must be refused with GOMEL_ERR_BUSY");
         rc = gomel_job_wait(j2);
         if (rc != GOMEL_OK) FAIL(rc, "gomel_job_wait (2)");
         rc = gomel_job_poll(j1, &fin);

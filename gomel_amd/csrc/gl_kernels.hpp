@@ -425,6 +425,12 @@ template <bool WIDE> struct StreamFlagSync {
 #ifndef GL_PAIRED
 #define GL_PAIRED 1
 #endif
+// k_gl_fused moves the SH new / finished rows two per dwordx4 through a DPP quad exchange from this frame length on; below it every row is its
+// own dwordx2 (the exchange's ~30 vector instructions per frame cost more than the saved memory instructions: -0.6 % at N 2048, -0.8 % at 1024,
+// -0.1 % at 4096 where the packing stays; bit-identical; profiles/r05/ab_fp64_round5_knobs.txt)
+#ifndef GL_ROWQUAD_MIN_N
+#define GL_ROWQUAD_MIN_N 4096
+#endif
 #ifndef GL_D_PAIRED
 #define GL_D_PAIRED 3
 #endif
@@ -1028,7 +1034,8 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
     // lane-pair addressing of two consecutive rows (see rows_from_quad): pair index of this lane's 16 bytes inside the row pair
     const bool even = (t & 1) == 0;
     const int lane_off = T * (t & 1) + (t & ~1);
-    constexpr int NPAIR = SH / 2;
+    constexpr bool ROWQUAD = N >= GL_ROWQUAD_MIN_N;
+    constexpr int NPAIR = ROWQUAD ? SH / 2 : 0;   // rows moved two per dwordx4 (otherwise every row as its own dwordx2, no DPP exchange)
     // Nyquist magnitudes of all the segment's frames: one load per wave (lane = frame, G <= kMaxSegFrames = 64), one v_readlane
     // per frame; narrower streams (several per wave) keep the per-frame vector load
     float nyq_all = 0.f;
@@ -1093,6 +1100,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         const bool any_next = more && d.has_next && row0 + SH - 1 >= rows_owned;
         v4f xq[NPAIR > 0 ? NPAIR : 1];
         v2f xs = v2f{0.f, 0.f};
+        v2f xr[SH];          // (!ROWQUAD only)
         v2f tl[SH];          // (read only under any_next: no zero-fill of 3 SH registers in every frame)
         float fl[SH];
         auto issue_rows = [&] {
@@ -1102,6 +1110,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
             for (int pq = 0; pq < NPAIR; pq++)
                 xq[pq] = *reinterpret_cast<const v4f*>(xin_p + T * (more ? row0 + 2 * pq : 0) + lane_off);   // clamped: unused when !more
             if constexpr (SH & 1) xs = xin_p[T * (more ? row0 + SH - 1 : 0) + t];
+            if constexpr (!ROWQUAD) {
+#pragma unroll
+                for (int jj = 0; jj < SH - (SH & 1); jj++) xr[jj] = xin_p[T * (more ? row0 + jj : 0) + t];
+            }
             if (any_next) {
 #pragma unroll
                 for (int jj = 0; jj < SH; jj++) {
@@ -1128,6 +1140,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #pragma unroll
         for (int pq = 0; pq < NPAIR; pq++) rows_from_quad(xq[pq], even, xin[KEEP + 2 * pq], xin[KEEP + 2 * pq + 1]);
         if constexpr (SH & 1) xin[KEEP + SH - 1] = xs;
+        if constexpr (!ROWQUAD) {
+#pragma unroll
+            for (int jj = 0; jj < SH - (SH & 1); jj++) xin[KEEP + jj] = xr[jj];
+        }
         if (any_next) {
 #pragma unroll
             for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] += tl[jj] * fl[jj];
@@ -1155,6 +1171,10 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
 #pragma unroll
             for (int pq = 0; pq < NPAIR; pq++) *reinterpret_cast<v4f*>(xo + T * (2 * pq) + lane_off) = quad_from_rows(yo[2 * pq], yo[2 * pq + 1], even);
             if constexpr (SH & 1) xo[T * (SH - 1) + t] = yo[SH - 1];
+            if constexpr (!ROWQUAD) {
+#pragma unroll
+                for (int j = 0; j < SH - (SH & 1); j++) xo[T * j + t] = yo[j];
+            }
             v2f nacc[KEEP];
 #pragma unroll
             for (int j = 0; j < KEEP; j++) {

@@ -1,0 +1,63 @@
+"""The exchange-layout facts the paired FFT form relies on (gl_fft.hpp, `PAIRED`; round 5), checked by plain arithmetic on the geometry
+constants read from the source: between a forward FFT's last reads and the following inverse's first writes, and between an inverse's
+last reads and the next forward's first writes, NO synchronisation is needed only because each slot involved is read and then written by
+the SAME lane and by no other.  Replaces, per frame, go-dsp's fft.FFTReal / fft.IFFT as the reference calls them (mel/mel.go:95,116)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "gomel_amd", "csrc", "gl_fft.hpp")).read()
+
+
+def geometries():
+    """{N: (R1, R2)} from the Geo<N> specialisations; the stride formulas from GeoBase (asserted to be what this test assumes)."""
+    geo = {int(n): (int(r1), int(r2)) for n, r1, r2 in re.findall(r"template <> struct Geo<(\d+)> : GeoBase<\d+, (\d+), (\d+)> \{\};", SRC)}
+    assert sorted(geo) == [256, 512, 1024, 2048, 4096]
+    for formula in ("SA = C1 + 32 / R1", "SAI = C1 + 16 / R1", "SB = B3 + R1", "B3 = C / R3", "T = C / P"):
+        assert formula in SRC, formula
+    return geo
+
+
+def test_pass3_slots_have_exactly_one_owner():
+    """Forward pass 3 reads lds[r * SB + bA], lds[r * SB + bB] (bA = t, bB = t ? B3 - t : B3 / 2) and the inverse's first pass writes the
+    same expressions: over all lanes t and rows r the slots are pairwise distinct, so a lane only ever overwrites what it alone has read."""
+    for N, (R1, R2) in geometries().items():
+        C = N // 2; T = C // 16; B3 = C // 8; SB = B3 + R1
+        seen = {}
+        for t in range(T):
+            bA, bB = t, (B3 - t if t else B3 // 2)
+            for r in range(8):
+                for slot in (r * SB + bA, r * SB + bB):
+                    assert slot not in seen, (N, t, r, seen[slot])
+                    seen[slot] = t
+        assert len(seen) == C                                    # every point of the frame, once
+
+
+def test_layout_a_with_one_stride_is_lane_private_at_the_frame_boundary():
+    """PAIRED bit 1: with ONE row stride (SAI) for layout A in both directions the inverse's last reads (lds[q * SAI + t1], t1 = t + T u)
+    and the next forward's first writes (the same expression) touch the same slots from the same lane, all slots distinct; and the stride
+    keeps every slot inside the stream's exchange area."""
+    for N, (R1, R2) in geometries().items():
+        C = N // 2; T = C // 16; C1 = C // R1; NB1 = 16 // R1; B3 = C // 8
+        SA, SAI, SB = C1 + 32 // R1, C1 + 16 // R1, B3 + R1
+        lds_slots = max(R1 * SA, 8 * SB)
+        owner = {}
+        for t in range(T):
+            for u in range(NB1):
+                t1 = t + T * u
+                assert t1 < C1 <= SAI
+                for q in range(R1):
+                    slot = q * SAI + t1
+                    assert slot < lds_slots and slot not in owner, (N, t, q)
+                    owner[slot] = t
+        assert len(owner) == C
+
+
+def test_fused_kernels_use_the_paired_forms():
+    """The product builds pair the FFTs in the fused kernels only (their frame loop touches the exchange area through these two calls
+    alone): the fp64 kernel at both joints, the fp32 kernel at the pass-3 joint (profiles/r05/ab_fp64_round5_knobs.txt)."""
+    k = open(os.path.join(ROOT, "gomel_amd", "csrc", "gl_kernels.hpp")).read()
+    assert "#define GL_PAIRED 1" in k and "#define GL_D_PAIRED 3" in k
+    assert k.count("fft_forward<G, GL_D_PAIRED>") == 2 and k.count("fft_inverse<G, GL_D_PAIRED>") == 1      # k_gl_fused_d (two twiddle forms of the forward call)
+    assert k.count("fft_forward<G, GL_PAIRED>") == 1 and k.count("fft_inverse<G, GL_PAIRED>") == 1          # k_gl_fused
+    assert len(re.findall(r"fft_(forward|inverse)<G, [A-Z_0-9]+>", k)) == 5                                  # nobody else: the any-hop kernels shift rows through the area in between

@@ -234,15 +234,43 @@ template <bool CONJ, int STRIDE, int CNT, class V> GL_DEV void apply_tw(V* v, co
     }
 }
 
+// fp64 forms of the butterflies' constant twiddles whose real and imaginary parts are both +-sqrt(1/2) (round 5): a (c -+ i s)
+// with |c| = |s| = k is k times a sum / difference of a's components, and the factor k rides on the multiply-adds of the radix-4 stage that
+// follows -- 2 adds + 4 multiply-adds where "complex multiply, then add and subtract" takes 4 + 4 (the fp32 kernels keep their packed asm forms).
+// (-DGL_D_FMATW=0 builds the plain "complex multiply, then radix-4" form for A/B: -48 fp64 instructions per frame and wave with it on)
+#ifndef GL_D_FMATW
+#define GL_D_FMATW 1
+#endif
+template <bool INV, class V> GL_DEV V q_pp(V a) { return INV ? V{a.x - a.y, a.x + a.y} : V{a.x + a.y, a.y - a.x}; }      // a (1 -+ i):  a twc(k, k) / k
+template <bool INV, class V> GL_DEV V q_mp(V a) { return INV ? V{-a.x - a.y, a.x - a.y} : V{a.y - a.x, -a.x - a.y}; }    // a (-1 -+ i): a twc(-k, k) / k
+// dft4 with a1 = k A, a3 = k B given as A, B
+template <bool INV, class V> GL_DEV void dft4_k13(V& a0, V& a1, V& a2, V& a3, double k_) {
+    typedef typename ScalarOf<V>::type S;
+    const V kk = V{(S)k_, (S)k_}, s02 = a0 + a2, d02 = a0 - a2, s = a1 + a3, d = mul_mi<INV>(a1 - a3);
+    a0 = vfma(s, kk, s02); a2 = vfma(s, -kk, s02); a1 = vfma(d, kk, d02); a3 = vfma(d, -kk, d02);
+}
+// dft4 with a2 = k Q given as Q (a1, a3 already twiddled)
+template <bool INV, class V> GL_DEV void dft4_k2(V& a0, V& a1, V& a2, V& a3, double k_) {
+    typedef typename ScalarOf<V>::type S;
+    const V kk = V{(S)k_, (S)k_}, s02 = vfma(a2, kk, a0), d02 = vfma(a2, -kk, a0), s13 = a1 + a3, d13 = mul_mi<INV>(a1 - a3);
+    a0 = s02 + s13; a1 = d02 + d13; a2 = s02 - s13; a3 = d02 - d13;
+}
+
 // In-place DFT of R registers at stride S in v[]; output q lands in v[q*S] (natural order).
 template <bool INV, int S, class V> GL_DEV void dft8(V* v) {
     V u0[4], u1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { u0[j] = v[j * S] + v[(j + 4) * S]; u1[j] = v[j * S] - v[(j + 4) * S]; }
+    dft4<INV>(u0[0], u0[1], u0[2], u0[3]);
+    if constexpr (GL_D_FMATW && __is_same(V, v2d)) {
+        u1[1] = q_pp<INV>(u1[1]); u1[3] = q_mp<INV>(u1[3]);
+        u1[2] = mul_mi<INV>(u1[2]);
+        dft4_k13<INV>(u1[0], u1[1], u1[2], u1[3], kS2);
+    } else {
     twc2<INV>(u1[1], kS2, kS2, u1[3], -kS2, kS2);
     u1[2] = mul_mi<INV>(u1[2]);
-    dft4<INV>(u0[0], u0[1], u0[2], u0[3]);
     dft4<INV>(u1[0], u1[1], u1[2], u1[3]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) { v[(2 * r) * S] = u0[r]; v[(2 * r + 1) * S] = u1[r]; }
 }
@@ -255,6 +283,21 @@ template <bool INV, int S, class V> GL_DEV void dft16(V* v) {
         dft4<INV>(u[j][0], u[j][1], u[j][2], u[j][3]);
     }
     // u[j][p] *= W16^{j p}
+    if constexpr (GL_D_FMATW && __is_same(V, v2d)) {
+        u[1][1] = twc<INV>(u[1][1], kC1, kS1); u[1][3] = twc<INV>(u[1][3], kS1, kC1);
+        u[3][1] = twc<INV>(u[3][1], kS1, kC1); u[3][3] = twc<INV>(u[3][3], -kC1, -kS1);
+        u[2][1] = q_pp<INV>(u[2][1]); u[2][3] = q_mp<INV>(u[2][3]);           // columns 1, 3: the k-type twiddle sits on a2
+        u[1][2] = q_pp<INV>(u[1][2]); u[3][2] = q_mp<INV>(u[3][2]);           // column 2: on a1 and a3
+        u[2][2] = mul_mi<INV>(u[2][2]);
+        dft4<INV>(u[0][0], u[1][0], u[2][0], u[3][0]);
+        dft4_k2<INV>(u[0][1], u[1][1], u[2][1], u[3][1], kS2);
+        dft4_k13<INV>(u[0][2], u[1][2], u[2][2], u[3][2], kS2);
+        dft4_k2<INV>(u[0][3], u[1][3], u[2][3], u[3][3], kS2);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[(p + 4 * r) * S] = u[r][p];
+    } else {
     twc2<INV>(u[1][1], kC1, kS1, u[1][2], kS2, kS2);
     twc2<INV>(u[1][3], kS1, kC1, u[2][1], kS2, kS2);
     u[2][2] = mul_mi<INV>(u[2][2]);
@@ -265,6 +308,7 @@ template <bool INV, int S, class V> GL_DEV void dft16(V* v) {
         dft4<INV>(u[0][p], u[1][p], u[2][p], u[3][p]);
 #pragma unroll
         for (int r = 0; r < 4; r++) v[(p + 4 * r) * S] = u[r][p];
+    }
     }
 }
 
@@ -755,15 +799,15 @@ GL_DEV v2d unit_phase_d(v2d x) {   // cmplx.Phase(0) = 0 -> (1, 0); scaled so th
     const double r = 1.0 / sqrt(y.x * y.x + y.y * y.y);
     return v2d{y.x * r, y.y * r};
 }
-// 1/(2 sqrt(p)) for p in the normal range: v_rsq_f64 (a 2^-23-grade seed) refined by two coupled Goldschmidt steps, 8 multiply-adds
-// where an IEEE 1.0 / sqrt(p) expands to ~26 instructions (the fp64 fused kernel is bound by its VALU instruction count)
-GL_DEV double half_rsqrt_d(double p) {
+// 1/sqrt(p) for p a positive normal number: v_rsq_f64 (16.5 cycles: four times an fp64 multiply-add, profiles/r05/mfma_f64_probe.txt) as the
+// seed and ONE third-order step, y (1 + e/2 + 3 e^2 / 8) with e = 1 - p y^2 (error ~ e^3: within 2 ulp for any seed good to 2^-20) -- five
+// multiply-adds where an IEEE 1.0 / sqrt(p) expands to ~26 instructions and the two coupled Goldschmidt steps of rounds 3-4 took seven;
+// no intermediate leaves the normal range when p is normal, so the caller's range test is "p is a positive normal number" (v_cmp_class_f64)
+GL_DEV double rsqrt_d(double p) {
     const double y = __builtin_amdgcn_rsq(p);
-    double g = p * y, h = 0.5 * y;                       // g -> sqrt(p), h -> 1 / (2 sqrt(p))
-    double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-    r = __builtin_fma(-h, g, 0.5);
-    return __builtin_fma(h, r, h);
+    const double e = __builtin_fma(-(p * y), y, 1.0);
+    const double c = __builtin_fma(e, 0.375, 0.5);
+    return __builtin_fma(y, c * e, y);
 }
 GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     v2d bc = v2d{b.x, -b.y};
@@ -771,19 +815,22 @@ GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     v2d q = cmul(w, rot_mi(d));
     v2d xk = p + q, xc = p - q;
     // Y = M X/|X| (mel/mel.go:98-102): unit phasor by reciprocal square root of the squared modulus; a modulus that is exactly zero
-    // (the reference: phase 0, Y = M) or whose square leaves the normal range takes the scaled form -- rare, wave-uniform branch
+    // (the reference: phase 0, Y = M) or whose square is not a positive normal number takes the scaled form -- rare, wave-uniform branch
     const double pk = __builtin_fma(xk.x, xk.x, xk.y * xk.y), pc = __builtin_fma(xc.x, xc.x, xc.y * xc.y);
-    v2d u, vv;
+    v2d e, f;
 #ifdef GOMEL_COUNT_ONLY   // instruction-count audits: the rare branch compiled out (never shipped)
     if (false) {
 #else
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fmin(pk, pc) > 1e-280) || !(fmax(pk, pc) < 1e280)) != 0, 0)) {
-        u = unit_phase_d(xk) * ma; vv = unit_phase_d(xc) * mb;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!__builtin_amdgcn_class(pk, 0x100) || !__builtin_amdgcn_class(pc, 0x100)) != 0, 0)) {
+        const v2d u = unit_phase_d(xk) * ma, vv = unit_phase_d(xc) * mb;
+        e = u + vv; f = u - vv;
 #endif
     } else {
-        u = xk * (half_rsqrt_d(pk) * (ma + ma)); vv = xc * (half_rsqrt_d(pc) * (mb + mb));
+        const double fk = rsqrt_d(pk) * ma, fc = rsqrt_d(pc) * mb;
+        const v2d vv = xc * fc, kk = v2d{fk, fk};
+        e = vfma(xk, kk, vv); f = vfma(xk, kk, -vv);       // Y[k] +- conj(Y[C-k]) with the first product riding on the multiply-adds
     }
-    v2d e = u + vv, o = cmulc(u - vv, w), io = rot_pi(o);
+    v2d o = cmulc(f, w), io = rot_pi(o);
     a = e + io;
     v2d t = e - io;
     b = v2d{t.x, -t.y};

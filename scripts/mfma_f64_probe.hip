@@ -61,6 +61,17 @@ template <int MODE> __global__ __launch_bounds__(256, 1) void k_probe(double* ou
                               REP4(F2C "v_mfma_f64_4x4x4_4b_f64 a[4:5], %10, %11, a[4:5]\n") REP4(F2D "v_mfma_f64_4x4x4_4b_f64 a[6:7], %10, %11, a[6:7]\n"))
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(m), "v"(ad), "v"(a), "v"(b)
                          : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7");
+        } else if constexpr (MODE >= 10) {   // 64 independent instances of ONE instruction (eight destinations in turn)
+#define ONE8(ins) ins " %0, %8\n " ins " %1, %8\n " ins " %2, %8\n " ins " %3, %8\n " ins " %4, %8\n " ins " %5, %8\n " ins " %6, %8\n " ins " %7, %8\n"
+#define TWO8(ins) ins " %0, %8, %9\n " ins " %1, %8, %9\n " ins " %2, %8, %9\n " ins " %3, %8, %9\n " ins " %4, %8, %9\n " ins " %5, %8, %9\n " ins " %6, %8, %9\n " ins " %7, %8, %9\n"
+            if constexpr (MODE == 10) asm volatile(REP4(ONE8("v_rsq_f64") ONE8("v_rsq_f64")) : FMAOPS);
+            if constexpr (MODE == 11) asm volatile(REP4(TWO8("v_mul_f64") TWO8("v_mul_f64")) : FMAOPS);
+            if constexpr (MODE == 12) asm volatile(REP4(TWO8("v_add_f64") TWO8("v_add_f64")) : FMAOPS);
+            if constexpr (MODE == 13) asm volatile(REP4(TWO8("v_min_f64") TWO8("v_min_f64")) : FMAOPS);
+            if constexpr (MODE == 14) asm volatile(REP4(ONE8("v_mov_b64") ONE8("v_mov_b64")) : FMAOPS);
+            if constexpr (MODE == 15) asm volatile(REP16("v_cmp_class_f64 vcc, %8, %10\n v_cmp_class_f64 vcc, %9, %10\n v_cmp_gt_f64 vcc, %8, %9\n v_cmp_lt_f64 vcc, %8, %9\n") : FMAOPS, "v"(0x100) : "vcc");
+            if constexpr (MODE == 16) asm volatile(REP4(ONE8("v_rcp_f64") ONE8("v_rcp_f64")) : FMAOPS);
+            if constexpr (MODE == 17) asm volatile(REP4(ONE8("v_sqrt_f64") ONE8("v_sqrt_f64")) : FMAOPS);
         } else if constexpr (MODE == 6) {
             int r0, r1, r2, r3;
             asm volatile(REP16("v_accvgpr_read_b32 %0, a0\n v_accvgpr_read_b32 %1, a1\n v_accvgpr_read_b32 %2, a2\n v_accvgpr_read_b32 %3, a3\n"
@@ -111,5 +122,13 @@ int main() {
     run<4>("64 MFMA back to back, 4 accumulators (AGPR C/D)", 64);
     run<5>("64 v_fma_f64 + 32 MFMA (AGPR C/D), one per 2", 64);
     run<6>("128 v_accvgpr_read", 128);
+    run<10>("64 v_rsq_f64", 64);
+    run<11>("64 v_mul_f64", 64);
+    run<12>("64 v_add_f64", 64);
+    run<13>("64 v_min_f64", 64);
+    run<14>("64 v_mov_b64", 64);
+    run<15>("64 v_cmp (32 class, 32 gt/lt) f64", 64);
+    run<16>("64 v_rcp_f64", 64);
+    run<17>("64 v_sqrt_f64", 64);
     return 0;
 }

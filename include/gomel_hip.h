@@ -229,7 +229,7 @@ int gomel_set_path(gomel_handle* h, int mode);
  *   0  (default) AUTOMATIC: the calibrated precision schedule gomel_auto_fp64_iterations(cfg, I).  Contract: calibrated, not
  *      guaranteed -- the call ends within 1e-4 RMS of the reference's float64 arithmetic except on about one utterance in 10^5
  *      (Griffin-Lim amplifies rounding without bound on a few inputs; measurements: DESIGN.md section 2);
- *   32 fp32 kernels for every iteration: the opt-in FAST mode (1.66x the default's rate at 60 iterations).  Typically 1e-6 from the
+ *   32 fp32 kernels for every iteration: the opt-in FAST mode.  Typically 1e-6 from the
  *      fp64 arithmetic, but ~1 % of 60-iteration utterances end beyond 1e-4;
  *   64 fp64 kernels for every iteration (~1e-13 from the fp64 restatement of the reference): the mode that is guaranteed on every input. */
 int gomel_set_precision(gomel_handle* h, int bits);

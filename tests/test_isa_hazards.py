@@ -144,3 +144,29 @@ def test_any_hop_fused_kernel_has_no_flat_loads_no_spills_no_waits_at_the_loop_t
         first_lds_write = next(i for i, l in enumerate(loop) if "ds_write_b64" in l)
         assert not any("s_waitcnt vmcnt" in l for l in loop[:first_lds_write]), inst      # nothing to wait for before the window goes to LDS
         assert sum("s_waitcnt vmcnt(0)" in l for l in loop) <= 2, inst                      # (one where the next window's loads are taken in)
+
+
+def test_fp64_fused_kernel_instruction_and_synchronisation_budget(isa):
+    """k_gl_fused_d<4096,5> is the dominant kernel of a default call and sits on an in-order issue floor: what moves its time
+    is the NUMBER of instructions a frame issues.  Pinned here, from the compiled code's frame loop (rare branches excluded): the fp64
+    arithmetic of round 5 (1 487 per frame and wave: third-order phasor step, class-based range test, sqrt(1/2) twiddles on the radix-4
+    multiply-adds; 1 613 before), the six polling loops a frame keeps of the eight it had (paired FFTs: gl_fft.hpp PAIRED = 3), sixteen
+    v_rsq_f64 and sixteen v_cmp_class_f64, 64 + 149 LDS data accesses of 16 bytes, no scratch, one wave per SIMD within 512 registers."""
+    text = "\n".join(isa)
+    m = re.search(r"\.name:\s+(_Z12k_gl_fused_dILi4096ELi5E\S*)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert m and int(m.group(3)) == 0 and int(m.group(2)) <= 512
+    start = next(i for i, l in enumerate(isa) if l.startswith("_Z12k_gl_fused_dILi4096ELi5EE") and ":" in l)
+    k = [l.strip() for l in isa[start:start + next(i for i, l in enumerate(isa[start:]) if "s_endpgm" in l) + 1]]
+    hdr = next(i for i, l in enumerate(k) if "This Loop Header: Depth=1" in l)
+    latch = max(i for i, l in enumerate(k[:hdr]) if re.match(r"^\.LBB\d+_\d+:", l))
+    label = k[latch].split(":")[0]
+    end = next(i for i in range(hdr, len(k)) if k[i].startswith("s_branch " + label))      # the back edge: what follows it are the rare branches' blocks
+    body = list(_instructions(k[latch:end + 1]))
+    ops = [b.split()[0] for b in body]
+    f64 = sum("f64" in o and not o.startswith("v_rsq") and not o.startswith("v_cmp") for o in ops)
+    assert 1400 <= f64 <= 1500, f64
+    assert ops.count("v_rsq_f64_e32") == 16 and sum(o.startswith("v_cmp_class_f64") for o in ops) == 16
+    assert sum(o == "ds_write_b128" for o in ops) == 64 and 140 <= sum(o == "ds_read_b128" for o in ops) <= 150
+    assert sum(o == "ds_read_b32" for o in ops) == 6 and sum(o == "ds_write_b32" for o in ops) == 6      # event counters: six waits, six arrives per frame
+    assert not any(o.startswith("scratch_") or o.startswith("flat_") for o in ops)
+    assert sum(o.startswith("v_accvgpr") for o in ops) <= 175 and sum(o.startswith("v_mov") for o in ops) <= 110   # parking / slide traffic: keep an eye on it

@@ -74,7 +74,7 @@ var ErrBusy = errors.New("gomel_hip: handle busy: submitted jobs have not been w
 // arithmetic is float64 throughout; the struct Mel stays field for field the reference's, so this is a package variable):
 // Fp64Auto (the default) = the library's calibrated schedule, C.gomel_auto_fp64_iterations: the first k(GriffinLimIterations)
 // iterations in fp64, the rest in fp32 -- within 1e-4 RMS of the float64 result on every utterance of the calibration sets (35 of 60,
-// 50 of 60 where frames overlap six-fold or more as in NewMel's defaults; both of the reference's shipped 2); 0 = the fp32 kernels throughout (the fast mode; on spectrograms that are not consistent ~1 % of
+// 50 of 60 where frames overlap six-fold or more as in NewMel's defaults, interpolated in the overlap between four- and six-fold; both of the reference's shipped 2); 0 = the fp32 kernels throughout (the fast mode; on spectrograms that are not consistent ~1 % of
 // 60-iteration utterances end more than 1e-4 RMS from the float64 result), -1 = the fp64 kernels throughout (agrees with float64
 // arithmetic on every input), k > 0 = the first k iterations in fp64, the rest in fp32 (C.gomel_set_precision_schedule).
 const Fp64Auto = math.MinInt32 // C.GOMEL_SCHEDULE_AUTO

@@ -549,11 +549,11 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
 }
 
 // the product form: no stamps
-template <class G, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
-    NoStamps st; fft_forward<G>(v, lds, t, tw, sync, st);
+template <class G, int PAIRED = 0, class V, class SyncT> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+    NoStamps st; fft_forward<G, PAIRED>(v, lds, t, tw, sync, st);
 }
-template <class G, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
-    NoStamps st; fft_inverse<G>(v, lds, t, tw, sync, st);
+template <class G, int PAIRED = 0, class V, class SyncT> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync) {
+    NoStamps st; fft_inverse<G, PAIRED>(v, lds, t, tw, sync, st);
 }
 
 // ---------------------------------------------------------------------------------------------- spectral step

@@ -722,13 +722,13 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
             load_mags_raw<G>(mraw, tl, mag + frame * G::C, nyq + frame);
             load_wn<G>(wn, tl, tb.wn);
         }
-        fft_forward<G>(v, my, tl, tw, sync);
+        fft_forward<G, GL_PAIRED>(v, my, tl, tw, sync);
         st.mark(3);
         if constexpr (LEAN) finish_mags(mr, mraw, t == 0);
         spectral_apply<G>(v, t, mr, wn);
         st.mark(4);
         if constexpr (LEAN) asm volatile("" : "+v"(tl));
-        fft_inverse<G>(v, my, tl, tw, sync);
+        fft_inverse<G, GL_PAIRED>(v, my, tl, tw, sync);
         st.mark(5);
         if constexpr (LEAN) {
             asm volatile("" : "+v"(tl));
@@ -899,10 +899,10 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restric
         load_wn<G>(wn, tl, tb.wnd);
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= w2[tl + T * j];
-        fft_forward<G>(v, my, tl, tw, sync);
+        fft_forward<G, GL_D_PAIRED>(v, my, tl, tw, sync);
         spectral_apply<G>(v, t, mr, wn);
         asm volatile("" : "+v"(tl));
-        fft_inverse<G>(v, my, tl, tw, sync);
+        fft_inverse<G, GL_D_PAIRED>(v, my, tl, tw, sync);
         asm volatile("" : "+v"(tl));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sentinel stores are through before any fresh pair goes out
 #pragma unroll

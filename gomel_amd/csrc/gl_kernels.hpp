@@ -20,6 +20,17 @@
 using namespace glfft;
 static_assert(glbig::kMaxN == kBigMaxN, "gl_types.hpp and gl_big.hpp agree on the longest frame");
 
+// Forward / inverse FFT as a pair (gl_fft.hpp, PAIRED) in every kernel whose loop touches the exchange area through those two calls alone: bit 0 = no synchronisation between forward pass 3's reads and
+// the inverse's first writes (same lane, same slots); bit 1 = nor between the inverse's last reads and the next frame's first writes (one row
+// stride for layout A in both directions).  Bit-identical results; k_gl_fused_d -0.7 ... -0.8 % with 3 on two boxes, k_gl_fused -0.4 ... -0.7 %
+// with 1 and +0.4 % with 3 (profiles/r05/ab_fp64_round5_knobs.txt).
+#ifndef GL_PAIRED
+#define GL_PAIRED 1      // fp32 kernels
+#endif
+#ifndef GL_D_PAIRED
+#define GL_D_PAIRED 3    // fp64 fused and persistent kernels (the generic and any-hop kernels take bit 0 only)
+#endif
+
 // =============================================================================================== device tables
 struct DevTables {
     glany::AnyTables any;  // generic-length path (gl_any.hpp); any.M == 0 when the register cores cover Resolut
@@ -285,11 +296,11 @@ __global__ __launch_bounds__(128) void k_gl_frames(const float* __restrict__ x, 
     load_wn<G>(wn, t, tb.wn);
 #pragma unroll
     for (int j = 0; j < 16; j++) { w[j] = w2[t + G::T * j]; v[j] *= w[j]; }
-    fft_forward<G>(v, my, t, tw, sync);
+    fft_forward<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
     MagRegs mr;
     finish_mags(mr, mraw, t == 0);
     spectral_apply<G>(v, t, mr, wn);
-    fft_inverse<G>(v, my, t, tw, sync);
+    fft_inverse<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
     if (live) {
         v2f* ys = reinterpret_cast<v2f*>(yw + frame * N);
 #pragma unroll
@@ -325,9 +336,9 @@ __global__ __launch_bounds__(128, GL_FRAMES_D_WAVES) void k_gl_frames_d(const do
     load_wn<G>(wn, t, tb.wnd);
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j] * w2[t + G::T * j];
-    fft_forward<G>(v, my, t, tw, sync);
+    fft_forward<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
     spectral_apply<G>(v, t, mr, wn);
-    fft_inverse<G>(v, my, t, tw, sync);
+    fft_inverse<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
     if (live) {
         v2d* ys = reinterpret_cast<v2d*>(yw + frame * N);
 #pragma unroll
@@ -418,21 +429,11 @@ template <bool WIDE> struct StreamFlagSync {
     GL_DEV void operator()() { arrive(); wait(); }
 };
 
-// The fused kernels' forward / inverse FFT as a pair (gl_fft.hpp, PAIRED): bit 0 = no synchronisation between forward pass 3's reads and
-// the inverse's first writes (same lane, same slots); bit 1 = nor between the inverse's last reads and the next frame's first writes (one row
-// stride for layout A in both directions).  Bit-identical results; k_gl_fused_d -0.7 ... -0.8 % with 3 on two boxes, k_gl_fused -0.4 ... -0.7 %
-// with 1 and +0.4 % with 3 (profiles/r05/ab_fp64_round5_knobs.txt).
-#ifndef GL_PAIRED
-#define GL_PAIRED 1
-#endif
 // k_gl_fused moves the SH new / finished rows two per dwordx4 through a DPP quad exchange from this frame length on; below it every row is its
 // own dwordx2 (the exchange's ~30 vector instructions per frame cost more than the saved memory instructions: -0.6 % at N 2048, -0.8 % at 1024,
 // -0.1 % at 4096 where the packing stays; bit-identical; profiles/r05/ab_fp64_round5_knobs.txt)
 #ifndef GL_ROWQUAD_MIN_N
 #define GL_ROWQUAD_MIN_N 4096
-#endif
-#ifndef GL_D_PAIRED
-#define GL_D_PAIRED 3
 #endif
 #ifndef GL_WIN_B128
 #define GL_WIN_B128 0
@@ -1358,13 +1359,13 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
             }
         }
         sync();   // the exchange area goes to the FFT now
-        fft_forward<G>(v, my, t, tw, sync);
+        fft_forward<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
         {
             MagRegs mr;
             finish_mags(mr, mraw, t == 0);
             spectral_apply<G>(v, t, mr, wn);
         }
-        fft_inverse<G>(v, my, t, tw, sync);
+        fft_inverse<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
         // The next frame's new samples have had two FFTs to arrive: take delivery HERE, before this frame's stores are issued.
         // vmcnt counts loads and stores in issue order and the stores below sit behind wave-uniform branches (their number is not
         // known at compile time), so a wait for these loads placed after them -- at the top of the next frame -- would be a
@@ -1771,7 +1772,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
             }
         }
         sync_reads_done(sync);   // the exchange area goes to the FFT now (its first write burst waits: sync_before_write)
-        fft_forward<G>(v, my, t, tw, sync);
+        fft_forward<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
@@ -1781,7 +1782,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
             }
             spectral_apply<G>(v, t, mr, wn);
         }
-        fft_inverse<G>(v, my, t, tw, sync);
+        fft_inverse<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
 #pragma unroll
         for (int j = 0; j < 16; j++) asm volatile("" : "+v"(xin[j]));   // the new samples are taken in BEFORE this frame's stores are issued
         __builtin_amdgcn_sched_barrier(0);

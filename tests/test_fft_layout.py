@@ -56,10 +56,11 @@ def test_layout_a_with_one_stride_is_lane_private_at_the_frame_boundary():
 def test_kernels_that_keep_their_exchange_area_to_themselves_use_the_paired_forms():
     """The product builds pair the FFTs where a frame (or iteration) loop touches the exchange area through these two calls alone: the fused
     kernels (fp64 at both joints, fp32 at the pass-3 joint: profiles/r05/ab_fp64_round5_knobs.txt) and the persistent kernels (same choice per
-    precision; their gather and stores go through global memory).  The any-hop kernels shift rows through the area in between and the
-    one-shot kernels (k_gl_frames, ToMel, phase) run one FFT per launch: they keep every synchronisation."""
+    precision; their gather and stores go through global memory).  The any-hop kernels shift rows through the area between frames and k_gl_frames
+    runs one forward / inverse pair per launch: they take the pass-3 joint only; ToMel / phase / the write-back run a single FFT."""
     k = open(os.path.join(ROOT, "gomel_amd", "csrc", "gl_kernels.hpp")).read()
     assert "#define GL_PAIRED 1" in k and "#define GL_D_PAIRED 3" in k
     assert k.count("fft_forward<G, GL_D_PAIRED>") == 3 and k.count("fft_inverse<G, GL_D_PAIRED>") == 2      # k_gl_fused_d (two twiddle forms of the forward call), k_gl_persist_d
     assert k.count("fft_forward<G, GL_PAIRED>") == 2 and k.count("fft_inverse<G, GL_PAIRED>") == 2          # k_gl_fused, k_gl_persist
-    assert len(re.findall(r"fft_(forward|inverse)<G, [A-Z_0-9]+>", k)) == 9
+    assert k.count("fft_forward<G, (GL_PAIRED & 1)>") == 4 and k.count("fft_inverse<G, (GL_PAIRED & 1)>") == 4   # pass-3 joint only: k_gl_frames[_d], k_gl_fused_any[_d]
+    assert len(re.findall(r"fft_(forward|inverse)<G, [^>]+>", k)) == 17

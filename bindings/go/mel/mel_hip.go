@@ -27,6 +27,7 @@ import (
 	"math/rand"
 	"runtime"
 	"sync"
+	"time"
 	"unsafe"
 
 	"github.com/r9y9/gossp/stft"
@@ -101,6 +102,9 @@ type engine struct {
 
 const maxEngines = 8
 
+// JobTimeout bounds FromMelBatch's wait for the device (gomel_job_wait_timeout); a call still running then returns ErrBusy.
+var JobTimeout = 10 * time.Minute
+
 var (
 	enginesMu sync.Mutex
 	engines   = map[engineKey]*engine{}
@@ -153,10 +157,18 @@ func (m *Mel) acquire() (*engine, error) {
 		if victim == nil {
 			break
 		}
-		C.gomel_destroy(victim.h)
+		if destroy(victim.h) != nil {
+			break // busy: stays in the cache, a later call evicts it
+		}
 		delete(engines, victimK)
 	}
 	return e, nil
+}
+
+// destroy frees a handle.  gomel_destroy refuses (GOMEL_ERR_BUSY) while submitted jobs have not been waited for -- the handle then
+// stays valid and must be kept: dropping it would leak it together with its device buffers.
+func destroy(h *C.gomel_handle) error {
+	return statusErr(C.gomel_destroy(h))
 }
 
 func (e *engine) release() {
@@ -170,8 +182,7 @@ func ReleaseEngines() {
 	enginesMu.Lock()
 	defer enginesMu.Unlock()
 	for k, e := range engines {
-		if e.refs == 0 {
-			C.gomel_destroy(e.h)
+		if e.refs == 0 && destroy(e.h) == nil {
 			delete(engines, k)
 		}
 	}
@@ -339,7 +350,26 @@ func (m *Mel) FromMelBatch(spectra [][][2]float64) ([][]float64, error) {
 		outs[u] = (*C.double)(unsafe.Pointer(&res[u][0]))
 		lens[u] = C.size_t(len(sp))
 	}
-	rc := C.gomel_from_mel_batch(e.h, C.size_t(n), &mels[0], &lens[0], &x0s[0], nil, &outs[0], nil)
+	// submit + bounded waits: a goroutine never blocks without end behind a device that has stopped answering.  A job that outlives
+	// JobTimeout is reported as ErrBusy and waited for in the background (it still owns the pinned slices: they stay pinned until it ends).
+	var job *C.gomel_job
+	rc := C.gomel_from_mel_batch_submit(e.h, C.size_t(n), &mels[0], &lens[0], &x0s[0], nil, &outs[0], nil, &job)
+	if rc == C.GOMEL_OK {
+		rc = C.gomel_job_wait_timeout(job, C.int64_t(JobTimeout/time.Millisecond))
+		if rc == C.GOMEL_ERR_BUSY {
+			held := pin
+			pin = runtime.Pinner{}
+			enginesMu.Lock()
+			e.refs++ // the background wait's own reference (the deferred release() balances this call's)
+			enginesMu.Unlock()
+			go func() {
+				C.gomel_job_wait(job)
+				held.Unpin()
+				e.release()
+			}()
+			return nil, ErrBusy
+		}
+	}
 	for _, sp := range spectra {
 		for i := range sp {
 			sp[i][0] = math.Exp(sp[i][0])

@@ -58,6 +58,7 @@ SYMBOLS = {
     "gomel_from_mel_batch_submit_f32": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.POINTER(c_float_p), c_size_p, ctypes.POINTER(c_float_p), c_u64_p,
                                                        ctypes.POINTER(c_float_p), c_size_p, ctypes.POINTER(_vp)]),
     "gomel_job_wait": (ctypes.c_int, [_vp]),
+    "gomel_job_wait_timeout": (ctypes.c_int, [_vp, ctypes.c_int64]),
     "gomel_set_call_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
     "gomel_job_poll": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     "gomel_plan_chunks": (ctypes.c_int, [_cfg_p, ctypes.c_size_t, c_size_p, c_size_p, ctypes.c_size_t, c_size_p]),
@@ -102,6 +103,7 @@ SYMBOLS = {
     "gomel_numa_bind_thread": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "gomel_device_count": (ctypes.c_int, []),
     "gomel_device_name": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "gomel_device_synchronize": (ctypes.c_int, [ctypes.c_int32]),
 }
 
 SCHEDULE_AUTO = -2 ** 31      # GOMEL_SCHEDULE_AUTO
@@ -122,13 +124,14 @@ _hip_runtime = None
 
 
 def _share_hip_runtime():
-    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so with the SONAME of the system
-    copy (libamdhip64.so.7) but asks for it by file name: if libgomel_hip.so pulled in /opt/rocm's copy first, a later
-    `import torch` would load a second runtime next to it (torch then reports no GPU, and device pointers / streams are not
-    interchangeable).  Loading torch's copy first, when there is one, makes the import order irrelevant: the library's
-    DT_NEEDED libamdhip64.so.7 then resolves to it.  GOMEL_HIP_RUNTIME=system skips this."""
+    """Which HIP runtime the library runs on.  libgomel_hip.so is linked against /opt/rocm's libamdhip64.so.7 (RUNPATH) and that is
+    what it gets by default -- the runtime the product ships on, the one a Go host loads.  A PyTorch-ROCm wheel bundles its own
+    libamdhip64.so with the same SONAME: when torch is ALREADY imported the dynamic loader resolves the library's DT_NEEDED to that
+    loaded copy by itself (one runtime per process, device pointers and streams interchangeable: torch interop works).  The one
+    order that does not work by itself is gomel_amd first, torch later -- torch would then bring a second runtime beside the system
+    one and report no GPU; a Python host that wants that order sets GOMEL_HIP_RUNTIME=torch, which loads torch's copy up front."""
     global _hip_runtime
-    if _hip_runtime is not None or "torch" in sys.modules or os.environ.get("GOMEL_HIP_RUNTIME", "") == "system":
+    if _hip_runtime is not None or "torch" in sys.modules or os.environ.get("GOMEL_HIP_RUNTIME", "system") != "torch":
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -142,6 +145,21 @@ def _share_hip_runtime():
             _hip_runtime = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             _hip_runtime = None
+
+
+def hip_runtime_path():
+    """Path of the libamdhip64 mapped into this process (from /proc/self/maps), None before the library is loaded.  More than one
+    copy mapped is reported as the paths joined by ' + ' -- a misconfiguration worth seeing (see _share_hip_runtime)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rstrip("\n").split(None, 5)[-1] if line.count("/") else ""
+                if "libamdhip64" in os.path.basename(path) and path not in found:
+                    found.append(path)
+    except OSError:
+        return None
+    return " + ".join(os.path.realpath(p) for p in found) if found else None
 
 
 def lib():

@@ -328,7 +328,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         TableHeader th;
         if (blob_bytes != need) { delete h; return GOMEL_ERR_BAD_TABLES; }
         memcpy(&th, blob, sizeof th);
-        if (th.magic != kMagic || th.version != GOMEL_HIP_ABI_VERSION || th.n != N || th.hop != cfg->window || th.k != K ||
+        if (th.magic != kMagic || (th.version != kTableFormat && th.version != 5 /* what the ABI-5 build stamped: same layout */) || th.n != N || th.hop != cfg->window || th.k != K ||
             th.fmin != cfg->mel_fmin || th.fmax != cfg->mel_fmax) { delete h; return GOMEL_ERR_BAD_TABLES; }
         const char* p = (const char*)blob + sizeof th;
         h->window.resize(N); memcpy(h->window.data(), p, (size_t)N * 8); p += (size_t)N * 8;
@@ -658,16 +658,11 @@ struct GateOrdinary {
     DeviceGate* g = nullptr;
     void enter(const gomel_handle* h, hipStream_t s) {
         g = &gate_of(h);
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->enqueueing++;
-        DeviceGate::prune(g->ps);
-        for (const DeviceGate::Ent& e : g->ps) if (hipStreamWaitEvent(s, e.ev, 0) != hipSuccess) (void)hipGetLastError();
+        g->enter_ordinary([s](hipEvent_t ev) { if (hipStreamWaitEvent(s, ev, 0) != hipSuccess) (void)hipGetLastError(); });
     }
     void leave(hipEvent_t ev, const gomel_batch* owner) {
         if (!g) return;
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->enqueueing--;
-        if (ev) DeviceGate::put(g->np, ev, owner);
+        g->leave_ordinary(ev ? &ev : nullptr, owner);
         g = nullptr;
     }
     ~GateOrdinary() { leave(nullptr, nullptr); }   // an early error return: whatever was queued is drained by the caller's error path
@@ -677,46 +672,32 @@ static int persist_units(gomel_batch* b) {
     const int census = std::max(1, persist_census(b->h, b->persist));
     return (int)std::min<int64_t>(1024, ((int64_t)b->n_wg * 1024 + census - 1) / census);
 }
-// A persistent run: takes the gate (and keeps its mutex) when the device is free of other work and has room; `locked` then stays set
-// until leave() has recorded the launch.  Caller holds h->mu and a DeviceGuard.
+// A persistent run: takes the gate (DeviceGateT::try_take_persistent keeps its mutex) when the device is free of other work and has
+// room; `locked` then stays set until leave() has recorded the launch.  Caller holds h->mu and a DeviceGuard.
 struct GatePersist {
     DeviceGate* g = nullptr;
     bool locked = false;
     bool take(gomel_batch* b) {
         g = &gate_of(b->h);
-        g->mu.lock();
-        DeviceGate::prune(g->np);
-        bool others = g->enqueueing != 0;
-        for (const DeviceGate::Ent& e : g->np) others |= e.owner != b;   // (its own earlier runs sit on the same stream: it runs behind them)
         const int u = b->persist_units ? 0 : persist_units(b);            // an earlier run of this batch still accounted: same stream, same share
-        if (others || g->persist_units + u > 1024) { g->mu.unlock(); g = nullptr; return false; }
-        g->persist_units += u;
+        if (!g->try_take_persistent(u, b)) { g = nullptr; return false; }
         if (u) b->persist_units = u;
         locked = true;
         return true;
     }
     void leave(gomel_batch* b, hipEvent_t ev) {   // ev recorded behind the launch (null: nothing was launched after all)
         if (!locked) return;
-        if (ev) DeviceGate::put(g->ps, ev, b);
         locked = false;
-        g->mu.unlock();
+        g->record_persistent(ev ? &ev : nullptr, b);
     }
-    ~GatePersist() { if (locked) { locked = false; g->mu.unlock(); } }
+    ~GatePersist() { if (locked) { locked = false; g->record_persistent(nullptr, nullptr); } }
 };
 static void persist_release(gomel_batch* b) {   // the batch's launches are known to have finished (or never ran)
     if (!b->persist_units) return;
-    DeviceGate& g = gate_of(b->h);
-    std::lock_guard<std::mutex> lk(g.mu);
-    g.persist_units -= b->persist_units;
+    gate_of(b->h).release_persistent(b->persist_units, b);
     b->persist_units = 0;
-    for (size_t i = 0; i < g.ps.size();) { if (g.ps[i].owner == b) g.ps.erase(g.ps.begin() + i); else i++; }
 }
-static void gate_forget(gomel_batch* b) {       // the batch (and its event) is going away
-    DeviceGate& g = gate_of(b->h);
-    std::lock_guard<std::mutex> lk(g.mu);
-    for (std::vector<DeviceGate::Ent>* v : {&g.np, &g.ps})
-        for (size_t i = 0; i < v->size();) { if ((*v)[i].owner == b) v->erase(v->begin() + i); else i++; }
-}
+static void gate_forget(gomel_batch* b) { gate_of(b->h).forget(b); }   // the batch (and its event) is going away
 
 // A persistent launch gave up (k_gl_persist: a workgroup waited 20 ms for a neighbour -- some other context held the CUs it
 // needed): nothing of its output is used.  x0 is still in d_x[0] (the kernel only reads it), so the batch is recomputed with the
@@ -1045,6 +1026,16 @@ int gomel_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int gomel_device_synchronize(int32_t device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return GOMEL_ERR_NO_DEVICE; }
+    if (device >= n) return GOMEL_ERR_BAD_CONFIG;
+    if (device < 0) { HIPCHK(hipDeviceSynchronize()); return GOMEL_OK; }
+    DeviceGuard dg(device); HIPCHK(dg.err);
+    HIPCHK(hipDeviceSynchronize());
+    return GOMEL_OK;
 }
 
 int gomel_create(const gomel_config* cfg, gomel_handle** out) { GOMEL_TRY return create_common(cfg, nullptr, 0, out); GOMEL_CATCH }
@@ -1663,12 +1654,18 @@ static int submit_guarded(gomel_handle* h, size_t n_utt, const void* const* mel,
     return GOMEL_OK;
 }
 
-static int job_wait_guarded(gomel_job* j) {
+// timeout_ms < 0: wait without bound (gomel_job_wait); otherwise poll until the deadline and hand the job back alive (GOMEL_ERR_BUSY)
+static int job_wait_guarded(gomel_job* j, int64_t timeout_ms = -1) {
     if (!j) return GOMEL_ERR_NULL;
     int rc = j->status;
     if (!j->completed) {
         DeviceGuard dg(j->h->device);
-        if (dg.err != hipSuccess || hipEventSynchronize(j->down) != hipSuccess) {
+        int q = 0;
+        if (dg.err == hipSuccess && timeout_ms >= 0) {
+            q = wait_event_bounded<HipEvOps>(j->down, timeout_ms);
+            if (q == 1) return GOMEL_ERR_BUSY;                          // still running: nothing is freed, the job stays valid
+        }
+        if (dg.err != hipSuccess || q < 0 || (timeout_ms < 0 && hipEventSynchronize(j->down) != hipSuccess)) {
             g_last_hip = (int)hipGetLastError(); rc = GOMEL_ERR_HIP;
             (void)hipStreamSynchronize(j->h->up_stream); (void)hipStreamSynchronize(j->h->stream); (void)hipStreamSynchronize(j->h->copy_stream);
             (void)hipGetLastError();
@@ -2112,6 +2109,9 @@ int gomel_from_mel_batch_submit_f32(gomel_handle* h, size_t n_utt, const float* 
 }
 int gomel_job_wait(gomel_job* job) {
     GOMEL_TRY return job_wait_guarded(job); GOMEL_CATCH
+}
+int gomel_job_wait_timeout(gomel_job* job, int64_t timeout_ms) {
+    GOMEL_TRY return job_wait_guarded(job, timeout_ms < 0 ? 0 : timeout_ms); GOMEL_CATCH
 }
 int gomel_job_poll(gomel_job* job, int* finished) {
     if (!job || !finished) return GOMEL_ERR_NULL;

@@ -37,6 +37,11 @@ struct TableHeader {
     double fmin, fmax;
 };
 static const uint32_t kMagic = 0x474d454cu;  // "GMEL"
+// The blob's OWN format number, stamped into TableHeader::version: it changes only when the blob's layout (TableHeader, window, BinRow
+// rows) or the table builder's semantics change -- not with the C ABI (ABI 4 -> 5 -> 6 added entry points; blobs written by those
+// builds stay interchangeable, which ranks running mixed library builds behind gomel_create_from_tables rely on).  4 = the value the
+// ABI-4 and ABI-5 builds stamped.
+static const uint32_t kTableFormat = 4;
 
 // Device-buffer cache of one handle.  hipFree of a multi-megabyte buffer is synchronous and slow (0.6 ms of the 0.75 ms that
 // one 342-frame, 2-iteration FromMel call took host-to-host went into freeing its working set), and the Go API is one call
@@ -197,7 +202,7 @@ static int auto_fp64_iterations(const gomel_config& c, int I) {
 }
 static void pack_tables(const gomel_config& c, int dom_status, const std::vector<double>& window, const std::vector<BinRow>& undo,
                         const std::vector<BinRow>& dom, void* blob) {
-    TableHeader th{kMagic, GOMEL_HIP_ABI_VERSION, c.resolut, c.window, c.num_mels, c.hann_periodic, dom_status, 0, c.mel_fmin, c.mel_fmax};
+    TableHeader th{kMagic, kTableFormat, c.resolut, c.window, c.num_mels, c.hann_periodic, dom_status, 0, c.mel_fmin, c.mel_fmax};
     char* p = (char*)blob;
     memcpy(p, &th, sizeof th); p += sizeof th;
     memcpy(p, window.data(), window.size() * 8); p += window.size() * 8;
@@ -461,6 +466,12 @@ struct PinWants {
 
 // ----------------------------------------------------------------------------------------------- device gate
 // EvOps: { typedef Event; static int query(Event) -> 0 done, 1 not ready, < 0 error (forgotten) } -- HIP events in the product, a fake in tests/host_stress.cpp
+// The whole admission protocol lives here, so that the sanitizer builds (no HIP) exercise the code the product runs:
+//   ordinary kernel work:  enter_ordinary(wait_for) ... enqueue ... leave_ordinary(&ev, owner)     (or leave_ordinary(nullptr, ..) after a sync)
+//   a persistent launch:   if (try_take_persistent(units, owner)) { ... enqueue ... record_persistent(&ev, owner); }   -- mu is HELD in between
+//                          release_persistent(units, owner) once the host has seen the launch finish
+// Invariant: a persistent launch is admitted only while no ordinary run of ANOTHER owner is enqueueing or in flight, and the shares of
+// the persistent launches in flight never exceed the device (1024 units).
 template <class EvOps> struct DeviceGateT {
     typedef typename EvOps::Event Event;
     struct Ent { Event ev; const void* owner; };
@@ -480,7 +491,70 @@ template <class EvOps> struct DeviceGateT {
         for (const Ent& e : v) if (e.ev == ev) return;   // re-recorded: the entry now stands for the latest record
         v.push_back(Ent{ev, owner});
     }
+    // Ordinary work is about to be enqueued: counts it, and hands every persistent launch still in flight to `wait_for` (the product
+    // makes its stream wait for that event, device-side).
+    template <class F> void enter_ordinary(F&& wait_for) {
+        std::lock_guard<std::mutex> lk(mu);
+        enqueueing++;
+        prune(ps);
+        for (const Ent& e : ps) wait_for(e.ev);
+    }
+    // ... has been enqueued.  ev: the event just recorded behind it (nullptr: it has been synchronised with, nothing stays in flight).
+    void leave_ordinary(const Event* ev, const void* owner) {
+        std::lock_guard<std::mutex> lk(mu);
+        enqueueing--;
+        if (ev) put(np, *ev, owner);
+    }
+    // A persistent launch of `units` (0: an earlier run of the same owner is still accounted -- same stream, same share).  true: admitted,
+    // and mu stays LOCKED until record_persistent, so that "nothing else in flight" still holds when the kernel reaches the queue.
+    bool try_take_persistent(int units, const void* owner) {
+        mu.lock();
+        prune(np);
+        bool others = enqueueing != 0;
+        for (const Ent& e : np) others |= e.owner != owner;   // (the owner's own earlier runs sit on the same stream: it runs behind them)
+        if (others || persist_units + units > 1024) { mu.unlock(); return false; }
+        persist_units += units;
+        return true;
+    }
+    // ev recorded behind the launch (nullptr: nothing was launched after all).  Unlocks mu.
+    void record_persistent(const Event* ev, const void* owner) {
+        if (ev) put(ps, *ev, owner);
+        mu.unlock();
+    }
+    // the owner's launches are known to have finished (or never ran)
+    void release_persistent(int units, const void* owner) {
+        std::lock_guard<std::mutex> lk(mu);
+        persist_units -= units;
+        for (size_t i = 0; i < ps.size();) { if (ps[i].owner == owner) ps.erase(ps.begin() + i); else i++; }
+    }
+    // the owner (and its events) is going away
+    void forget(const void* owner) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (std::vector<Ent>* v : {&np, &ps})
+            for (size_t i = 0; i < v->size();) { if ((*v)[i].owner == owner) v->erase(v->begin() + i); else i++; }
+    }
 };
+
+// ----------------------------------------------------------------------------------------------- bounded host waits
+// gomel_job_wait_timeout: poll an event until it is done or `timeout_ms` have passed -- a server goroutine must not block forever
+// behind a device that stopped answering.  Polls with short sleeps that grow to 1 ms (a job is tens of milliseconds long).
+// Returns 0 done, 1 still running at the deadline, < 0 the query failed.  Clock and sleep are injectable (tests/host_stress.cpp).
+struct SteadyWaitClock {
+    static int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static void sleep_us(int64_t us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); }
+};
+template <class EvOps, class Clock = SteadyWaitClock> static int wait_event_bounded(typename EvOps::Event ev, int64_t timeout_ms) {
+    const int64_t deadline = Clock::now_us() + (timeout_ms < 0 ? 0 : timeout_ms) * 1000;
+    int64_t nap = 50;
+    for (;;) {
+        const int q = EvOps::query(ev);
+        if (q != 1) return q;
+        const int64_t left = deadline - Clock::now_us();
+        if (left <= 0) return 1;
+        Clock::sleep_us(std::min(nap, left));
+        nap = std::min<int64_t>(nap * 2, 1000);
+    }
+}
 
 // ----------------------------------------------------------------------------------------------- NUMA locality of host threads
 // The CPUs of the NUMA node a PCI device hangs off, from sysfs (root injectable: the CPU tests run on a fake tree).  Used by the

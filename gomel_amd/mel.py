@@ -22,16 +22,37 @@ class ErrFileNotLoaded(Exception):
         super().__init__("wavNotLoaded")
 
 
+class DevicePointer:
+    """`numel` float64 elements in the memory of the handle's device at address `ptr` (from hipMalloc, another library, a pipeline stage
+    that keeps its spectrograms in HBM): what the batch calls take wherever they take an array (include/gomel_hip.h "Pointers").  The
+    caller owns the memory and must have finished writing it (the library copies on its own streams)."""
+    is_cuda = True
+    dtype = "float64"
+
+    def __init__(self, ptr, numel):
+        self._ptr, self._numel = int(ptr), int(numel)
+
+    def data_ptr(self):
+        return self._ptr
+
+    def numel(self):
+        return self._numel
+
+    def is_contiguous(self):
+        return True
+
+
 def _is_device_tensor(a):
-    """A torch CUDA tensor: its memory is handed to the library as a device pointer (include/gomel_hip.h "Pointers")."""
+    """A torch CUDA tensor or a DevicePointer: its memory is handed to the library as a device pointer (include/gomel_hip.h "Pointers")."""
     return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
 
 
 def _device_ptr(a, numel, what):
-    import torch
-    if a.dtype != torch.float64 or not a.is_contiguous() or a.numel() != numel:
-        raise ValueError("%s: device tensors must be contiguous float64 with %d elements" % (what, numel))
-    torch.cuda.current_stream(a.device).synchronize()   # the library copies on its own stream
+    if str(a.dtype).replace("torch.", "") != "float64" or not a.is_contiguous() or a.numel() != numel:
+        raise ValueError("%s: device memory must be contiguous float64 with %d elements" % (what, numel))
+    if not isinstance(a, DevicePointer):
+        import torch
+        torch.cuda.current_stream(a.device).synchronize()   # the library copies on its own stream
     return ctypes.cast(ctypes.c_void_p(a.data_ptr()), c_double_p)
 
 
@@ -56,8 +77,12 @@ class Engine:
             check(L.gomel_create_from_tables(ctypes.byref(cfg), buf, len(tables), ctypes.byref(self._h)), "gomel_create_from_tables")
 
     def close(self):
+        """gomel_destroy.  A handle with submitted jobs that have not been waited for refuses (GOMEL_ERR_BUSY): it STAYS valid and this
+        raises -- wait for the jobs, then close again (dropping it here would leak the handle and its device buffers)."""
         if self._h:
-            _lib.lib().gomel_destroy(self._h)
+            rc = _lib.lib().gomel_destroy(self._h)
+            if rc == 13:
+                raise GomelError(rc, "gomel_destroy")
             self._h = ctypes.c_void_p()
 
     def __del__(self):
@@ -371,10 +396,19 @@ class Job:
         check(_lib.lib().gomel_job_poll(self._j, ctypes.byref(f)), "gomel_job_poll")
         return bool(f.value)
 
-    def wait(self):
+    def wait(self, timeout_ms=None):
+        """Blocks until the waveforms have landed.  With `timeout_ms` (gomel_job_wait_timeout): raises TimeoutError when the job is still
+        running at the deadline -- the job stays valid (wait again); any other outcome finishes and frees it."""
         if self._j:
-            j, self._j = self._j, None
-            check(_lib.lib().gomel_job_wait(j), "gomel_job_wait")
+            if timeout_ms is None:
+                j, self._j = self._j, None
+                check(_lib.lib().gomel_job_wait(j), "gomel_job_wait")
+            else:
+                rc = _lib.lib().gomel_job_wait_timeout(self._j, int(timeout_ms))
+                if rc == 13:                                   # GOMEL_ERR_BUSY: still running, still ours
+                    raise TimeoutError("gomel_job_wait_timeout: the job is still running after %d ms" % int(timeout_ms))
+                self._j = None
+                check(rc, "gomel_job_wait_timeout")
         return self._bound.views
 
     def __del__(self):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GOMEL_HIP_ABI_VERSION 5
+#define GOMEL_HIP_ABI_VERSION 6
 
 typedef enum gomel_status {
     GOMEL_OK = 0,
@@ -45,7 +45,8 @@ typedef enum gomel_status {
     GOMEL_ERR_BAD_TABLES = 10,    /* injected table blob does not match the configuration                         */
     GOMEL_ERR_TOO_SHORT = 11,     /* ToMel: padded input shorter than one frame                                   */
     GOMEL_ERR_NO_MEMORY = 12,     /* host allocation failed (C++ exceptions never cross the boundary)             */
-    GOMEL_ERR_BUSY = 13           /* gomel_destroy with submitted jobs not yet waited for: the handle stays valid  */
+    GOMEL_ERR_BUSY = 13           /* gomel_destroy with submitted jobs not yet waited for (the handle stays valid);
+                                     gomel_job_wait_timeout: the job is still running at the deadline (it stays valid) */
 } gomel_status;
 
 /* Mirrors `type Mel` (mel/mel.go:10-27).  YReverse, VolumeBoost and SampleRate only matter to the PNG/WAV
@@ -169,6 +170,11 @@ int gomel_from_mel_batch_submit(gomel_handle* h, size_t n_utt, const double* con
 int gomel_from_mel_batch_submit_f32(gomel_handle* h, size_t n_utt, const float* const* mel_pairs, const size_t* n_pairs,
                                     const float* const* x0, const uint64_t* seeds, float* const* out, const size_t* out_cap, gomel_job** job);
 int gomel_job_wait(gomel_job* job);
+/* The bounded wait a server uses (a goroutine must not block forever behind a device that has stopped answering): as gomel_job_wait,
+ * but gives up after `timeout_ms` milliseconds with GOMEL_ERR_BUSY -- the job is then STILL VALID and still owns the caller's buffers
+ * (wait again, poll, or give the process up; a job cannot be cancelled: its copies may be in flight).  Any other status: the job is
+ * finished and freed exactly as by gomel_job_wait.  timeout_ms <= 0 = one poll. */
+int gomel_job_wait_timeout(gomel_job* job, int64_t timeout_ms);
 int gomel_job_poll(gomel_job* job, int* finished);
 int gomel_set_call_mode(gomel_handle* h, int mode);
 
@@ -304,6 +310,10 @@ int gomel_numa_cpus(const char* sysfs_root, const char* pci_bus_id, int32_t* nod
 int gomel_numa_bind_thread(const char* sysfs_root, const char* pci_bus_id, int32_t* node, int32_t* n_bound);
 int gomel_device_count(void);
 int gomel_device_name(const gomel_handle* h, char* buf, size_t cap);
+/* Blocks until every piece of work queued on `device` by this process has finished (hipDeviceSynchronize with the calling thread's
+ * device saved and restored): what a timing harness or a host without its own HIP binding brackets a measurement with.
+ * device = -1: the calling thread's current device. */
+int gomel_device_synchronize(int32_t device);
 
 #ifdef __cplusplus
 }

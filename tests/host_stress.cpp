@@ -137,7 +137,11 @@ struct FakeEvOps {
 };
 typedef DeviceGateT<FakeEvOps> FakeGate;
 static FakeGate g_fake_gate;
-static std::atomic<int> g_ordinary_in_flight{0};   // ordinary runs between enter and the completion of their event
+static std::atomic<int> g_ordinary_in_flight{0};   // ordinary runs between enter_ordinary and the completion of their event
+static std::atomic<long> g_persist_admitted{0}, g_persist_refused{0}, g_waits_seen{0};
+// Drives the PRODUCT's admission protocol (DeviceGateT::enter_ordinary / leave_ordinary / try_take_persistent / record_persistent /
+// release_persistent / forget -- the very methods gomel_hip.hip's GateOrdinary and GatePersist call) from four threads, and asserts its
+// invariant at the only place it can be observed without a race: under the gate's mutex, right after a persistent launch was admitted.
 static void gate_worker(int id, int iters) {
     Rng r(5000 + id);
     std::vector<std::atomic<int>> flags(8);
@@ -145,45 +149,61 @@ static void gate_worker(int id, int iters) {
     int owner_tag = id;
     for (int i = 0; i < iters; i++) {
         std::atomic<int>& flag = flags[r.below(flags.size())];
-        if (r.below(3) != 0) {   // an ordinary run: enter (prune persistent launches), enqueue, record its event, complete a little later
-            {
-                std::lock_guard<std::mutex> lk(g_fake_gate.mu);
-                g_fake_gate.enqueueing++;
-                FakeGate::prune(g_fake_gate.ps);
-            }
+        if (r.below(3) != 0) {   // an ordinary run: enter (told which persistent launches to wait for), enqueue, record its event, complete a little later
+            g_fake_gate.enter_ordinary([](FakeEvent e) { g_waits_seen++; CHECK(e.done != nullptr); });
             g_ordinary_in_flight++;
             flag = 0;
-            {
-                std::lock_guard<std::mutex> lk(g_fake_gate.mu);
-                g_fake_gate.enqueueing--;
-                FakeGate::put(g_fake_gate.np, FakeEvent{&flag}, &owner_tag);
-            }
+            const FakeEvent ev{&flag};
+            g_fake_gate.leave_ordinary(&ev, &owner_tag);
             if (r.below(2)) std::this_thread::yield();
             g_ordinary_in_flight--;
-            flag = 1;             // (decrement first: an observer that still sees the event pending may see the count already lowered, never the reverse)
+            flag = 1;             // (decrement first: an observer that sees the event done has seen the count lowered)
         } else {                 // a persistent run: admitted only while nothing ordinary is enqueueing or in flight and the share fits
             const int units = 128 + (int)r.below(900);
-            g_fake_gate.mu.lock();
-            FakeGate::prune(g_fake_gate.np);
-            bool others = g_fake_gate.enqueueing != 0;
-            for (const FakeGate::Ent& e : g_fake_gate.np) others |= e.owner != &owner_tag;
-            if (others || g_fake_gate.persist_units + units > 1024) { g_fake_gate.mu.unlock(); continue; }
-            g_fake_gate.persist_units += units;
+            if (!g_fake_gate.try_take_persistent(units, &owner_tag)) { g_persist_refused++; continue; }
+            // admitted: the gate's mutex is held until record_persistent.  Every ordinary run that has entered has also left (enqueueing
+            // == 0) and every event of another owner has completed -- and this worker's own runs completed before it came here.
+            CHECK(g_ordinary_in_flight.load() == 0);
+            CHECK(g_fake_gate.enqueueing == 0);
             CHECK(g_fake_gate.persist_units <= 1024);
+            for (const FakeGate::Ent& e : g_fake_gate.np) CHECK(e.owner == &owner_tag);
+            g_persist_admitted++;
             flag = 0;
-            FakeGate::put(g_fake_gate.ps, FakeEvent{&flag}, &owner_tag);
-            g_fake_gate.mu.unlock();
+            const FakeEvent ev{&flag};
+            g_fake_gate.record_persistent(&ev, &owner_tag);
             if (r.below(2)) std::this_thread::yield();
             flag = 1;
-            std::lock_guard<std::mutex> lk(g_fake_gate.mu);
-            g_fake_gate.persist_units -= units;
-            for (size_t k = 0; k < g_fake_gate.ps.size();) { if (g_fake_gate.ps[k].owner == &owner_tag) g_fake_gate.ps.erase(g_fake_gate.ps.begin() + k); else k++; }
+            g_fake_gate.release_persistent(units, &owner_tag);
         }
     }
-    // this worker's flags die with it: nothing of its may stay in the gate
-    std::lock_guard<std::mutex> lk(g_fake_gate.mu);
-    for (std::vector<FakeGate::Ent>* v : {&g_fake_gate.np, &g_fake_gate.ps})
-        for (size_t k = 0; k < v->size();) { if ((*v)[k].owner == &owner_tag) v->erase(v->begin() + k); else k++; }
+    g_fake_gate.forget(&owner_tag);   // this worker's flags die with it: nothing of its may stay in the gate
+}
+
+// ---- gomel_job_wait_timeout's polling loop on a fake event and a fake clock ---------------------------------------------------------
+struct FakeClock {
+    static int64_t& t() { static thread_local int64_t v = 0; return v; }
+    static int& sleeps() { static thread_local int v = 0; return v; }
+    static int64_t now_us() { return t(); }
+    static void sleep_us(int64_t us) { CHECK(us > 0 && us <= 1000); t() += us; sleeps()++; }
+};
+struct CountdownEvOps {   // "done" after a number of queries; a negative count makes the query fail
+    typedef int* Event;
+    static int query(int* left) { if (*left < 0) return -1; if (*left == 0) return 0; (*left)--; return 1; }
+};
+static void bounded_wait_checks() {
+    int left = 0;
+    FakeClock::t() = 0; FakeClock::sleeps() = 0;
+    CHECK((wait_event_bounded<CountdownEvOps, FakeClock>(&left, 1000) == 0) && FakeClock::sleeps() == 0);   // already done: no sleep
+    left = 5;
+    CHECK((wait_event_bounded<CountdownEvOps, FakeClock>(&left, 1000) == 0) && FakeClock::sleeps() == 5);   // done after five polls
+    left = 1 << 30; FakeClock::t() = 0; FakeClock::sleeps() = 0;
+    CHECK((wait_event_bounded<CountdownEvOps, FakeClock>(&left, 20) == 1));                                  // still running at the deadline
+    CHECK(FakeClock::t() == 20000 && FakeClock::sleeps() >= 20 && FakeClock::sleeps() < 40);                  // slept exactly up to it, in naps of at most 1 ms
+    left = 1 << 30; FakeClock::sleeps() = 0;
+    CHECK((wait_event_bounded<CountdownEvOps, FakeClock>(&left, 0) == 1) && FakeClock::sleeps() == 0);       // timeout 0 = one poll
+    CHECK((wait_event_bounded<CountdownEvOps, FakeClock>(&left, -5) == 1) && FakeClock::sleeps() == 0);      // negative = the same
+    left = -1;
+    CHECK((wait_event_bounded<CountdownEvOps, FakeClock>(&left, 1000) == -1));                               // a failing query ends the wait
 }
 
 int main(int argc, char** argv) {
@@ -206,9 +226,11 @@ int main(int argc, char** argv) {
     CHECK(calls > 0);
     CHECK(pool_bad.load() == 0);
     CHECK(g_fake_gate.persist_units == 0 && g_fake_gate.enqueueing == 0 && g_fake_gate.np.empty() && g_fake_gate.ps.empty());
+    CHECK(g_persist_admitted.load() > 0 && g_persist_refused.load() > 0);   // both outcomes of the admission were exercised
+    bounded_wait_checks();
     CHECK(gomel_debug_pin_backend(0) == GOMEL_OK);
     for (char* b : g_buf) free(b);
-    printf("host_stress: %ld failures; pin backend calls %ld, violations %ld, live %ld/%ld; pool self-test violations %d\n", g_fail.load(), calls, viol, live_reg, live_be,
-           pool_bad.load());
+    printf("host_stress: %ld failures; pin backend calls %ld, violations %ld, live %ld/%ld; pool self-test violations %d; gate: %ld persistent launches admitted, %ld refused, %ld waits handed out\n",
+           g_fail.load(), calls, viol, live_reg, live_be, pool_bad.load(), g_persist_admitted.load(), g_persist_refused.load(), g_waits_seen.load());
     return g_fail.load() ? 1 : 0;
 }

@@ -45,7 +45,7 @@ def test_default_config_is_newmel(L):
     assert L.gomel_default_config(ctypes.byref(c)) == 0
     assert (c.num_mels, c.window, c.resolut, c.griffin_lim_iterations) == (160, 256, 2048, 2)     # mel/mel.go:30-41
     assert (c.mel_fmin, c.mel_fmax, c.tune_mul, c.tune_add) == (0.0, 8000.0, 1.0, 0.0)
-    assert L.gomel_abi_version() == 5
+    assert L.gomel_abi_version() == 6
 
 
 def test_length_helpers_match_oracle(L, oracle):
@@ -127,6 +127,9 @@ def test_automatic_precision_schedule_table(L):
     assert "#define GOMEL_SCHEDULE_AUTO (-2147483647 - 1)" in src
     assert L.gomel_get_precision(None, 60, None) == 7 and L.gomel_set_call_mode(None, 1) == 7 and L.gomel_job_wait(None) == 7
     assert L.gomel_job_poll(None, None) == 7
+    assert L.gomel_job_wait_timeout(None, 10) == 7                                                # round 6: the bounded wait
+    if L.gomel_device_count() == 0:
+        assert L.gomel_device_synchronize(0) == 9 and L.gomel_device_synchronize(-1) == 9          # GOMEL_ERR_NO_DEVICE, never a crash
     j = ctypes.c_void_p()
     assert L.gomel_from_mel_batch_submit(None, 1, None, None, None, None, None, None, ctypes.byref(j)) == 7 and not j
 

@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
 
 
 def test_sharded_results_equal_single_process_gloo_world2(oracle):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp          # (stdlib: the process running pytest never imports torch, tests/conftest.py)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -167,6 +167,7 @@ def test_full_size_config3_properties(oracle):
         assert rms(out1[u] - want) < RMS_TOL, (u, rms(out1[u] - want))
 
 
+@pytest.mark.stress
 def test_concurrent_callers_share_and_separate_handles(oracle):
     """The reference is plain Go and callable from many goroutines; the handle serialises calls on itself with a mutex and sets
     the device on every entry.  Eight host threads hammer one shared handle and one private handle each."""
@@ -233,6 +234,7 @@ def test_aliased_and_repeated_host_buffers(oracle):
     assert rms(outs[0] - want) < RMS_TOL
 
 
+@pytest.mark.stress
 def test_threads_sharing_one_input_buffer(oracle):
     """Several threads, each with its own handle, pass the SAME large input array at the same time (pinned per call through a
     reference-counted registry inside the library)."""
@@ -261,10 +263,9 @@ def test_threads_sharing_one_input_buffer(oracle):
     assert not errors, errors[:3]
 
 
-def test_device_resident_inputs_and_outputs(oracle):
-    """Spectrograms, x0 and the output may live in HBM (torch CUDA tensors -> device pointers through the C ABI): same bits
-    as the host-buffer route, mixed host/device batches included."""
-    import torch
+def _device_resident_case(oracle, to_device, empty_device, to_host, wrong_dtype=None):
+    """Spectrograms, x0 and the output may live in HBM (device pointers through the C ABI): same bits as the host-buffer route, mixed
+    host / device batches included.  `to_device(ndarray)`, `empty_device(n)` and `to_host(obj)` supply the device memory."""
     import gomel_amd
     m = mel_obj(FIELDS["towav_n4096"], GriffinLimIterations=2)
     e = m.engine()
@@ -275,20 +276,79 @@ def test_device_resident_inputs_and_outputs(oracle):
     b.upload(mels, x0s, [1, 2, 3])
     b.run()
     want = b.download()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    d_mels = [torch.from_numpy(x).to(dev) for x in mels]
-    d_x0s = [torch.from_numpy(x0s[0]).to(dev), None, x0s[2]]                               # device, absent, host
+    d_mels = [to_device(x) for x in mels]
+    d_x0s = [to_device(x0s[0]), None, x0s[2]]                                               # device, absent, host
     b.upload([d_mels[0], mels[1], d_mels[2]], d_x0s, [1, 2, 3])                             # mixed host / device
     b.run()
-    d_outs = [torch.empty(L, dtype=torch.float64, device=dev) for L in lens]
+    d_outs = [empty_device(L) for L in lens]
     got = b.download([d_outs[0], np.empty(lens[1]), d_outs[2]])
     for g, w in zip(got, want):
-        g = g.cpu().numpy() if hasattr(g, "cpu") else g
+        g = g if isinstance(g, np.ndarray) else to_host(g)
         assert np.array_equal(g, w)
-    with pytest.raises(ValueError):
-        b.upload([d_mels[0].float(), mels[1], d_mels[2]], None, [1, 2, 3])                  # wrong dtype on the device
+    if wrong_dtype is not None:
+        with pytest.raises(ValueError):
+            b.upload([wrong_dtype(d_mels[0]), mels[1], d_mels[2]], None, [1, 2, 3])         # wrong dtype on the device
     b.close()
     e.close()
+
+
+def test_device_resident_inputs_and_outputs(oracle, hip):
+    """Device pointers from the runtime's own allocator (hipMalloc through ctypes: what a Go / C++ host with its own HIP binding hands
+    over), wrapped in the minimal object gomel_amd.mel takes for device memory (data_ptr / is_cuda / dtype / numel)."""
+    import ctypes
+    import gomel_amd
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    held = []
+
+    def empty_device(n):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), 8 * int(n)) == 0
+        held.append(p)
+        return gomel_amd.DevicePointer(p.value, int(n))
+
+    def to_device(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        d = empty_device(a.size)
+        assert hip.hipMemcpy(d.data_ptr(), a.ctypes.data, a.nbytes, 1) == 0                  # hipMemcpyHostToDevice
+        return d
+
+    def to_host(d):
+        out = np.empty(d.numel())
+        assert hip.hipMemcpy(out.ctypes.data, d.data_ptr(), out.nbytes, 2) == 0              # hipMemcpyDeviceToHost
+        return out
+
+    try:
+        _device_resident_case(oracle, to_device, empty_device, to_host)
+    finally:
+        for p in held:
+            hip.hipFree(p)
+
+
+def _torch_device_resident_child(rep):
+    """Child process (tests/_children.py): torch is imported, then the library; torch CUDA tensors go through the C ABI as device
+    pointers (two allocators on one runtime; torch copies on its legacy null stream, the library on its own non-blocking streams)."""
+    import torch
+    import gomel_oracle
+    rep.stage("torch.cuda init")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.zeros(1, device=dev)
+    rep.stage("library calls")
+    _device_resident_case(gomel_oracle, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                          lambda n: torch.empty(n, dtype=torch.float64, device=dev), lambda t: t.cpu().numpy(), wrong_dtype=lambda t: t.float())
+    import gomel_amd
+    rep.result({"runtime": gomel_amd.hip_runtime_path()})
+
+
+@pytest.mark.torch_child
+@pytest.mark.guard(700)
+def test_device_resident_torch_tensors_in_a_child_process():
+    """The same case with torch CUDA tensors, in a child process that imports torch first (the one order in which a Python host shares
+    torch's HIP runtime with the library without asking, gomel_amd/_lib.py)."""
+    import _children
+    got = _children.run_child(_torch_device_resident_child)
+    assert got["runtime"] and "torch" in got["runtime"] and " + " not in got["runtime"], got   # ONE runtime in that process: torch's copy
 
 
 def test_working_buffers_reused_across_calls_leave_no_trace(oracle):

@@ -148,6 +148,7 @@ def test_timeout_recomputes_with_the_generic_kernels(oracle, monkeypatch):
     e.close(); eg.close()
 
 
+@pytest.mark.stress
 def test_repeated_runs_and_a_busy_chip_never_change_a_bit(oracle):
     """The hazard of an in-launch exchange is a RARE stale read.  One batch object run 150 times (its buffers keep the previous
     run's frames: exactly what a stale read would pick up), alone and while a second handle keeps the chip busy with the fused
@@ -233,6 +234,7 @@ def test_fp64_single_utterance_matches_the_oracle_to_rounding(oracle):
     b.close(); e.close()
 
 
+@pytest.mark.stress
 def test_concurrent_persistent_launches_of_several_handles_share_the_chip(oracle):
     """Each persistent launch needs all its workgroups resident; two of different handles, half resident each, would wait for one
     another until both give up.  The library accounts queued persistent launches per device and sends a run that finds no room

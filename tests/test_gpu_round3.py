@@ -75,9 +75,8 @@ def test_c_program_drives_the_gpu_entry_points_like_the_cgo_shim(oracle, tmp_pat
 
 
 # ------------------------------------------------------------------------------------------------ RCCL on a group of one rank
-def _nccl_world1_main(port, q):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def _nccl_world1_main(rep, port):
+    """Child process (tests/_children.py has imported torch)."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
@@ -86,49 +85,45 @@ def _nccl_world1_main(port, q):
     from gomel_amd import dist as gd
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    rep.stage("init_process_group(nccl)")
     dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port, device_id=dev)   # bench.py's init
     try:
         m = gomel_amd.NewMel()
         for k, v in dict(S, GriffinLimIterations=4).items():
             setattr(m, k, v)
         m.Device = 0
+        rep.stage("table broadcast over RCCL")
         eng = gd.create_engine_broadcast(lambda tables=None: gomel_amd.Engine(m._config(), tables=tables), 0, 1, device=dev, force_collective=True)
         blob = gd.broadcast_bytes(eng.export_tables(), 0, 1, device=dev, force_collective=True)   # what a rank > 0 receives
         eng2 = gomel_amd.Engine(m._config(), tables=blob)
         mels = [go.random_logmel(f, 80, seed=i) for i, f in enumerate([30, 7, 64])]
+        rep.stage("FromMel")
         a = eng.from_mel_batch(mels, None, [0, 1, 2])
         b = eng2.from_mel_batch(mels, None, [0, 1, 2])
+        rep.stage("all_reduce / all_gather_object / barrier")
         t = torch.tensor([1.25], dtype=torch.float64, device=dev)                                 # bench.py's MAX over ranks
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gathered = [None]
         dist.all_gather_object(gathered, 3.5)
         dist.barrier()
-        q.put(("ok", blob == eng.export_tables(), all(np.array_equal(x, y) for x, y in zip(a, b)), float(t.item()), gathered, dist.get_backend()))
+        rep.result((blob == eng.export_tables(), all(np.array_equal(x, y) for x, y in zip(a, b)), float(t.item()), gathered, dist.get_backend()))
         eng.close(); eng2.close()
-    except Exception as ex:  # noqa: BLE001
-        q.put(("error", repr(ex)))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.torch_child
+@pytest.mark.guard(700)
 def test_table_broadcast_through_rccl_on_a_group_of_one_rank():
     """the one collective of the path is the broadcast of the table blob over RCCL.  One GPU cannot show N ranks, but it
     can run the SAME call path once: torch.distributed with the nccl backend (= RCCL) and device_id, a uint8 CUDA-tensor broadcast
     that is forced through the collective (dist.broadcast_bytes short-circuits a world of one otherwise), the float64 all_reduce(MAX)
     and all_gather_object bench.py uses -- and a handle built from the bytes that came back computes the same bits."""
-    import torch.multiprocessing as mp
+    import _children
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_nccl_world1_main, args=(port, q))
-    p.start()
-    got = q.get(timeout=300)
-    p.join(timeout=120)
-    assert got[0] == "ok", got
-    assert p.exitcode == 0
-    _, same_blob, same_bits, tmax, gathered, backend = got
+    same_blob, same_bits, tmax, gathered, backend = _children.run_child(_nccl_world1_main, (port,))
     assert backend == "nccl" and same_blob and same_bits and tmax == 1.25 and gathered == [3.5]
 
 
@@ -205,38 +200,6 @@ def test_precision_schedule_is_fp64_then_fp32(oracle, fields, frames):
         pers = None                                             # hop not a multiple of 4: the persistent kernel does not take it
     if pers is not None:
         assert tmp["fast_path"] == 2 and all(np.array_equal(a, b) for a, b in zip(pers, gens))
-
-
-# ------------------------------------------------------------------------------------------------ configs[4]: one rank's shard
-def test_config5_one_rank_shard_of_the_8192_corpus(oracle, coracle):
-    """BASELINE configs[4] shards an 8192-utterance corpus over 8 GPUs: 1024 utterances x 400 frames per rank.  This is
-    rank 3's shard (utterances 3072 ... 4095, seeds = global indices) on the one GPU here, through gomel_from_mel_batch in the
-    calls of 256 bench.py makes: lengths, finiteness, call-to-call determinism, independence from the position inside a call
-    (an utterance gives the same bits alone in another call order), and utterances against the oracle."""
-    import gomel_amd
-    fields = dict(T, GriffinLimIterations=60)
-    U, F, K, first = 1024, 400, 192, 3072
-    m = mel_obj(fields)
-    eng = m.engine()
-    cfg = oracle.MelConfig(**fields)
-    L = oracle.out_len(cfg, F * K)
-    mels, seeds = cfg3_inputs(U, F, K, first=first)
-    outs = []
-    for b0 in range(0, U, 256):
-        outs += eng.from_mel_batch(mels[b0:b0 + 256], None, seeds[b0:b0 + 256])
-    assert len(outs) == U and all(o.shape == (L,) and np.isfinite(o).all() for o in outs)
-    again = eng.from_mel_batch(mels[512:768], None, seeds[512:768])
-    assert all(np.array_equal(a, b) for a, b in zip(again, outs[512:768]))                      # call-to-call bitwise
-    pick = [0, 517, 1023]
-    want, _ = coracle.from_mel_batch(cfg, [mels[u] for u in pick], [oracle.x0_splitmix(seeds[u], L) for u in pick], threads=3)
-    errs = [rms(outs[u] - w) for u, w in zip(pick, want)]
-    print("config 5 shard (utterances %d..%d): rms vs oracle %s" % (first, first + U - 1, ["%.2e" % e for e in errs]))
-    assert np.median(errs) < 1e-5 and max(errs) < 1e-3          # fp32 kernels: the statistical bound of DESIGN.md section 2 (no drift, no systematic error)
-    eng.set_precision(64)                                       # ... and the same three in the mode that promises the tolerance on every utterance
-    o64 = eng.from_mel_batch([mels[u] for u in pick], None, [seeds[u] for u in pick])
-    assert max(rms(a - w) for a, w in zip(o64, want)) < 1e-9
-    sig = np.array([rms(o) for o in outs])
-    assert 0.1 < sig.min() and sig.max() < 0.5                                                  # every utterance a signal of the expected level (0.25)
 
 
 # ------------------------------------------------------------------------------------------------ 64-bit mode at hops that are no multiple of N/16

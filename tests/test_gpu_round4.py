@@ -182,12 +182,25 @@ def test_submitted_jobs_equal_the_whole_batch_bit_for_bit(oracle, mode, monkeypa
     jd = eng.submit_bound(bound[0], sets[0][1])
     assert gomel_amd._lib.lib().gomel_destroy(eng._h) == 13 and b"busy" in gomel_amd._lib.lib().gomel_strerror(13)
     assert all(np.array_equal(a, b) for a, b in zip(jd.wait(), refs[0]))
+    # Engine.close() on a busy handle raises and KEEPS the handle (round 6: dropping it leaked the handle and its device buffers)
+    jc = eng.submit_bound(bound[1], sets[1][1])
+    with pytest.raises(gomel_amd.GomelError) as busy:
+        eng.close()
+    assert busy.value.status == 13 and eng._h
+    # the bounded wait (gomel_job_wait_timeout): a deadline of one poll on a job that has just been submitted comes back as BUSY with the
+    # job still valid; a generous one returns the result; a finished job is freed by it exactly as by gomel_job_wait
+    with pytest.raises(TimeoutError):
+        jc.wait(timeout_ms=0)
+    assert not jc.done() or True                                       # (it may have finished since; either way it is still ours)
+    assert all(np.array_equal(a, b) for a, b in zip(jc.wait(timeout_ms=60000), refs[1]))
+    assert jc.done() and jc.wait() is not None                        # freed: further waits are no-ops on the Python side
     # errors surface at submit, nothing is left in flight
     with pytest.raises(gomel_amd.GomelError):
         eng.submit_bound(eng.bind_buffers([np.zeros((191, 2))], [np.zeros(8192)]), [0])
     eng.close()
 
 
+@pytest.mark.stress
 def test_two_threads_calling_in_whole_batch_mode_get_the_sequential_bits(oracle, monkeypatch):
     """SURVEY 8(b) "handle usable from concurrent goroutines": two host threads call gomel_from_mel_batch in a loop on ONE handle in
     whole-batch call mode -- their calls pipeline (copies of one beside the kernels of the other) -- and every result equals the

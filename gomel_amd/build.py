@@ -52,12 +52,21 @@ def build(force=False, verbose=False, out=OUT, extra_flags=()):
     with tempfile.TemporaryDirectory(prefix="gomel_build_") as tmp:
         host_o, hip_o = os.path.join(tmp, "gomel_host.o"), os.path.join(tmp, "gomel_hip.o")
         cxx = shutil.which("g++") or shutil.which("c++")
-        host = subprocess.Popen([cxx] + HOST_FLAGS + list(extra_flags) + ["-c", HOST_SRC, "-o", host_o]) if cxx else None   # beside the device compile
-        _run([hipcc()] + HIP_FLAGS + list(extra_flags) + ["-c", SRC, "-o", hip_o], verbose)
-        if host is None:
-            _run([hipcc(), "-x", "c++"] + HOST_FLAGS + list(extra_flags) + ["-c", HOST_SRC, "-o", host_o], verbose)   # no g++: the host pass of hipcc's clang
-        elif host.wait():
-            raise subprocess.CalledProcessError(host.returncode, "g++ gomel_host.cpp")
+        host_cmd = ([cxx] if cxx else [hipcc(), "-x", "c++"]) + HOST_FLAGS + list(extra_flags) + ["-c", HOST_SRC, "-o", host_o]   # (no g++: the host pass of hipcc's clang)
+        if verbose:
+            print(" ".join(host_cmd), file=sys.stderr)
+        host = subprocess.Popen(host_cmd, stderr=subprocess.PIPE, text=True)                 # beside the device compile
+        try:
+            _run([hipcc()] + HIP_FLAGS + list(extra_flags) + ["-c", SRC, "-o", hip_o], verbose)
+            _, host_err = host.communicate()
+            if host_err.strip():
+                print(host_err, file=sys.stderr)
+            if host.returncode:
+                raise subprocess.CalledProcessError(host.returncode, host_cmd)
+        finally:
+            if host.poll() is None:        # the device compile failed: do not leave the host compile writing into a directory that is about to go
+                host.kill()
+                host.communicate()
         _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", hip_o, host_o], verbose)
     os.replace(out + ".tmp", out)
     return out

@@ -45,7 +45,10 @@ struct DevTables {
     const double* windowd; // [N]
     const BinRow* undo;    // [N/2]
     const BinRow* dom;     // [K]
+    unsigned* sync_err;    // host-pinned word: a two-wave stream's wait for its partner wave gave up (StreamFlagSync); null: not reported
+    unsigned sync_cap;     // polls such a wait may spend (kSyncCapDefault; GOMEL_SYNC_CAP at gomel_create: tests)
 };
+constexpr unsigned kSyncCapDefault = 1u << 24;   // ~100 cycles per poll: about a second -- a partner wave that far behind has stopped
 
 // Every supported Resolut in one place: expands the statement with NN a compile-time constant.
 #define GOMEL_DISPATCH_N(n, ...)                                   \
@@ -408,21 +411,45 @@ __global__ __launch_bounds__(256) void k_ola(const UttDesc* __restrict__ utts, i
 // the wave's data accesses: the LDS executes a wave's instructions in order), `wait()` polls the partner's word until it shows the same
 // count.  Both waves run the same event sequence, so "the partner has reached my latest event" is the one condition ever needed.
 // WIDE = false (streams within one wave): program order is the synchronisation, as everywhere else.
+// BOUNDED (round 6): a wait polls at most `cap` times.  Both waves of a stream run the same event sequence and are resident together, so the
+// partner is never more than a few hundred cycles behind -- unless it has stopped (a fault in its half of the frame): then this wave would
+// spin until the queue is torn down under it.  Instead the first wait that runs out of polls raises the handle's `err` word (host-pinned;
+// the host turns it into GOMEL_ERR_HIP at its next synchronisation with the device and the call's results are discarded), sets cap = 0 --
+// every later wait then gives up after ONE poll -- and the wave runs through to the end of its segment: the grid always drains.
+// The poll count is wave-uniform (SGPR arithmetic inside the poll loop only: nothing on the path of a wait that finds its partner there).
+#ifndef GL_FLAG_RELAXED
+#define GL_FLAG_RELAXED 0   // measured on k_gl_fused_d<4096,5>: 1.4541 (relaxed) vs 1.4483 ms (volatile), n = 6 each, profiles/r06/two_frames_in_flight/ab_flag.txt: no gain, the volatile form stays
+#endif
 template <bool WIDE> struct StreamFlagSync {
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     unsigned* mine; unsigned* other; unsigned& ev;
+    unsigned& cap; unsigned* err;
     GL_DEV void arrive() {
         if constexpr (WIDE) {
             ev++;
             asm volatile("" ::: "memory");
+#if GL_FLAG_RELAXED
+            // every lane writes the same value: one ds_write_b32.  A RELAXED workgroup-scope atomic store instead of a volatile one: the
+            // memory legalizer puts s_waitcnt lgkmcnt(0) behind every volatile LDS access, so each "my reads are issued" signal waited for
+            // those very reads to land; the LDS executes a wave's instructions in order, which is all the ordering the protocol needs
+            __hip_atomic_store(mine, ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
             *(volatile lds_u32*)mine = ev;      // every lane writes the same value: one ds_write_b32
+#endif
             asm volatile("" ::: "memory");
         } else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     }
     GL_DEV void wait() {
         if constexpr (WIDE) {
             asm volatile("" ::: "memory");
-            while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {}
+            unsigned polls = 0;
+            while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {
+                if (__builtin_expect(++polls > cap, 0)) {
+                    cap = 0;
+                    if (err && (threadIdx.x & 63) == 0) *(volatile unsigned*)err = 1u;
+                    break;
+                }
+            }
             asm volatile("" ::: "memory");
         }
     }
@@ -1494,8 +1521,8 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
     // together by every barrier and to send their 16 x ds_read_b128 bursts into the one LDS pipe at the same moment -- and the
     // read -> write points become split-phase (the wait sits in front of the next write burst, where it never stalls):
     // 1.534 -> 1.378 ms per launch at config 3 (profiles/r03/ab_fp64_flagsync.txt).  Streams inside one wave need neither.
-    unsigned ev = 0;
-    StreamFlagSync<(Geo<N>::T > 64)> sync{cnt_sh + 2 * stream + ((threadIdx.x % T) >> 6), cnt_sh + 2 * stream + (((threadIdx.x % T) >> 6) ^ 1), ev};
+    unsigned ev = 0, sync_cap = tb.sync_cap;
+    StreamFlagSync<(Geo<N>::T > 64)> sync{cnt_sh + 2 * stream + ((threadIdx.x % T) >> 6), cnt_sh + 2 * stream + (((threadIdx.x % T) >> 6) ^ 1), ev, sync_cap, tb.sync_err};
     int seg = blockIdx.x * STREAMS + stream;
     const bool live = seg < n_segs;
     if (!live) seg = n_segs - 1;

@@ -81,7 +81,8 @@ struct gomel_handle {
     // costs one 20 ms attempt in thousands of calls
     uint64_t batches_seen = 0, persist_retry_at = 0;
     uint32_t persist_backoff = 64;
-    unsigned* err_slab = nullptr; // [kErrSlots] pinned
+    unsigned* err_slab = nullptr; // [kErrSlots + 1] pinned; the last word: a fused kernel's bounded partner wait gave up (DevTables::sync_err)
+    unsigned sync_cap = kSyncCapDefault;   // polls such a wait may spend (GOMEL_SYNC_CAP at gomel_create: the tests force a give-up with 0)
     std::vector<int> err_free;
     int persist_nap = 2;          // s_sleep(1) units between two looks at a slot that still shows the sentinel (GOMEL_PERSIST_NAP)
     unsigned persist_ticks = kPersistSpinTicks;   // spin limit in 100 MHz ticks (GOMEL_PERSIST_TICKS: the tests force a timeout with 0)
@@ -301,9 +302,21 @@ static int upload_tables(gomel_handle* h) {
     h->dt.tw1d = (const v2d*)(d + o_tw1d); h->dt.tw2d = (const v2d*)(d + o_tw2d); h->dt.wnd = (const v2d*)(d + o_wnd);
     h->dt.windowd = (const double*)(d + o_wind);
     h->dt.undo = (const BinRow*)(d + o_undo); h->dt.dom = (const BinRow*)(d + o_dom);
+    h->dt.sync_err = h->err_slab ? h->err_slab + kErrSlots : nullptr;   // (hipHostMalloc memory: the device writes it in place)
+    h->dt.sync_cap = h->sync_cap;
     return GOMEL_OK;
 }
 
+// A fused kernel's bounded wait for its partner wave gave up since the last look (StreamFlagSync, gl_kernels.hpp): whatever that launch
+// wrote is garbage.  Called wherever the host has just synchronised with the handle's work: the call in hand comes back as GOMEL_ERR_HIP
+// (gomel_last_hip_error() = hipErrorLaunchTimeOut), the word is cleared and the handle stays usable -- a wave only stops waiting when
+// its partner has stopped running, so recomputing is the caller's decision, not something to retry silently.
+static int sync_err_check(gomel_handle* h) {
+    if (!h->err_slab || !h->err_slab[kErrSlots]) return GOMEL_OK;
+    h->err_slab[kErrSlots] = 0;
+    g_last_hip = (int)hipErrorLaunchTimeOut;
+    return GOMEL_ERR_HIP;
+}
 
 static int create_common(const gomel_config* cfg, const void* blob, size_t blob_bytes, gomel_handle** out) {
     if (!cfg || !out) return GOMEL_ERR_NULL;
@@ -352,8 +365,8 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
         if (h->copy_stream) hipStreamDestroy(h->copy_stream);
         delete h; return GOMEL_ERR_HIP;
     }
-    if (hipHostMalloc((void**)&h->err_slab, kErrSlots * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) {
-        memset(h->err_slab, 0, kErrSlots * sizeof(unsigned));
+    if (hipHostMalloc((void**)&h->err_slab, (kErrSlots + 1) * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) {
+        memset(h->err_slab, 0, (kErrSlots + 1) * sizeof(unsigned));
         for (int i = kErrSlots - 1; i >= 0; i--) h->err_free.push_back(i);
     } else { h->err_slab = nullptr; (void)hipGetLastError(); }   // no slab: the persistent path is simply never chosen
     // GOMEL_PRECISION = auto | 32 | 64: the mode a handle STARTS in (default auto), for deployments that choose the fast mode -- or
@@ -361,6 +374,7 @@ static int create_common(const gomel_config* cfg, const void* blob, size_t blob_
     if (const char* e = getenv("GOMEL_PRECISION")) h->precision = !strcmp(e, "32") ? kPrecFp32 : !strcmp(e, "64") ? kPrecFp64 : kPrecAuto;
     if (const char* e = getenv("GOMEL_PERSIST_TICKS")) h->persist_ticks = (unsigned)strtoul(e, nullptr, 10);
     if (const char* e = getenv("GOMEL_PERSIST_NAP")) h->persist_nap = atoi(e);
+    if (const char* e = getenv("GOMEL_SYNC_CAP")) h->sync_cap = (unsigned)strtoul(e, nullptr, 10);
     rc = upload_tables(h);
     if (rc) { if (h->err_slab) hipHostFree(h->err_slab); hipStreamDestroy(h->stream); hipStreamDestroy(h->copy_stream); hipStreamDestroy(h->up_stream); if (h->d_blob) hipFree(h->d_blob); delete h; return rc; }
     *out = h;
@@ -965,6 +979,7 @@ static int batch_run_impl(gomel_batch* b, gomel_timing* tm) {
         HIPCHK(hipEventRecord(b->ev[3], s));
         HIPCHK(hipEventSynchronize(b->ev[3]));
         if (persist) persist_release(b);   // seen to finish
+        if (int se = sync_err_check(h)) return se;
         if (persist && I > 0 && h->err_slab[b->err_slot]) return persist_redo(b, tm);
         if (persist && I > 0) h->persist_backoff = 64;
         HIPCHK(hipEventElapsedTime(&tm->total_ms, b->ev[0], b->ev[3]));
@@ -1403,7 +1418,8 @@ int gomel_batch_sync(gomel_batch* b) {
     std::lock_guard<std::mutex> lk(b->h->mu);
     DeviceGuard dg(b->h->device); HIPCHK(dg.err);
     HIPCHK(hipStreamSynchronize(b->h->stream));
-    return persist_verify(b);
+    const int rv = persist_verify(b);
+    return rv ? rv : sync_err_check(b->h);
 }
 
 static int batch_download_guarded(gomel_batch* b, void* const* out, const size_t* out_cap, int io32) {
@@ -1423,7 +1439,7 @@ static int batch_download_guarded(gomel_batch* b, void* const* out, const size_t
     for (size_t u = 0; u < b->n_utt; u++)
         HIPCHK(hipMemcpyAsync(out[u], (char*)b->d_out + (size_t)b->utts[u].xoff * b->esz, (size_t)b->utts[u].len * b->esz, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return GOMEL_OK;
+    return sync_err_check(h);
 }
 
 int gomel_batch_destroy(gomel_batch* b) {
@@ -1561,6 +1577,7 @@ static int from_mel_batch_chunked(gomel_handle* h, size_t n_utt, const void* con
             for (hipEvent_t e : down) if (e) hipEventDestroy(e);
         }
     }   // pins dropped here, after every stream has drained
+    if (!rc) { std::lock_guard<std::mutex> lk(h->mu); rc = sync_err_check(h); }
     return rc;
 }
 
@@ -1670,6 +1687,7 @@ static int job_wait_guarded(gomel_job* j, int64_t timeout_ms = -1) {
             (void)hipStreamSynchronize(j->h->up_stream); (void)hipStreamSynchronize(j->h->stream); (void)hipStreamSynchronize(j->h->copy_stream);
             (void)hipGetLastError();
         }
+        if (!rc) { std::lock_guard<std::mutex> lk(j->h->mu); rc = sync_err_check(j->h); }   // (handle-wide: with several jobs in flight the first wait behind a give-up reports it)
     }
     job_drop(j);
     return rc;

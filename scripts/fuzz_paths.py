@@ -9,7 +9,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import gomel_amd
 GEOMS = {"T": dict(NumMels=192, MelFmax=16000.0, Window=1280, Resolut=4096), "S": dict(NumMels=80, MelFmax=8000.0, Window=256, Resolut=1024),
-         "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), "Q": dict(NumMels=64, MelFmax=8000.0, Window=128, Resolut=512)}
+         "D": dict(NumMels=160, MelFmax=8000.0, Window=256, Resolut=2048), "Q": dict(NumMels=64, MelFmax=8000.0, Window=128, Resolut=512),
+         # hops OFF the N/16 grid: the any-hop fused kernels (path 3), even and odd
+         "A": dict(NumMels=80, MelFmax=8000.0, Window=400, Resolut=2048), "B": dict(NumMels=80, MelFmax=8000.0, Window=300, Resolut=1024),
+         "C": dict(NumMels=96, MelFmax=16000.0, Window=441, Resolut=4096)}
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 rms = lambda a: float(np.sqrt(np.mean(a * a)))
@@ -28,7 +31,7 @@ for c in range(cases):
         engines[key] = (m, m.engine())
     e = engines[key][1]
     K = GEOMS[g]["NumMels"]
-    cap = {"T": 1200, "S": 5000, "D": 2600, "Q": 9000}[g]
+    cap = {"T": 1200, "S": 5000, "D": 2600, "Q": 9000, "A": 2600, "B": 5000, "C": 1800}[g]
     U = int(rng.integers(1, 9))
     frames = [int(rng.integers(1, max(2, cap // U * 2))) for _ in range(U)]
     mels = [rng.uniform(math.log(1e-5), math.log(50.0), size=(f * K, 2)) for f in frames]
@@ -55,4 +58,7 @@ for c in range(cases):
             print("MISMATCH case %d geom %s I %d mode %s frames %s path %d: rms diff %.3e" % (c, g, I, sched, frames, fp, rms(a - r)), flush=True)
             break
 print("fuzz: %d cases, paths taken %s (0 generic, 1 fused, 2 persistent, 3 fused any-hop), mismatches %d" % (cases, paths, bad))
-sys.exit(1 if bad else 0)
+missing = [p for p in (0, 1, 2, 3) if not paths.get(p)]
+if missing:
+    print("fuzz: paths never taken: %s -- the draw does not cover the kernels, not a pass" % missing)
+sys.exit(1 if bad or missing else 0)

@@ -442,14 +442,23 @@ template <bool WIDE> struct StreamFlagSync {
     GL_DEV void wait() {
         if constexpr (WIDE) {
             asm volatile("" ::: "memory");
-            unsigned polls = 0;
-            while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {
-                if (__builtin_expect(++polls > cap, 0)) {
+#ifdef GL_SYNC_UNBOUNDED   // (A/B builds only: what the cap costs)
+            while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {}
+#else
+            // The FIRST poll is the unbounded loop's own code -- read, wait, compare, a branch that is not taken when the partner is there -- and
+            // everything about the bound sits behind that branch, out of line: +0.4 ... 0.8 % on k_gl_fused_d<4096,5> against the unbounded
+            // loop.  A bounded loop IN FRONT cost +1.5 % as a two-exit C++ loop (the compiler rebuilds it around exit flags: two more taken
+            // branches per poll), +2.0 % spelled in assembly; an assembly loop behind the first poll +1.4 % (profiles/r06/ab_cap.txt).
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev, 0)) {
+                unsigned polls = 0;
+                bool there;
+                do { there = __builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) >= ev; } while (!there && ++polls <= cap);
+                if (!there) {                                 // ran out of polls: the partner wave has stopped
                     cap = 0;
-                    if (err && (threadIdx.x & 63) == 0) *(volatile unsigned*)err = 1u;
-                    break;
+                    if (err) *(volatile unsigned*)err = 1u;   // (every lane stores the same word: no divergent branch)
                 }
             }
+#endif
             asm volatile("" ::: "memory");
         }
     }

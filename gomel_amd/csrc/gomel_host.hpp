@@ -544,7 +544,7 @@ struct SteadyWaitClock {
     static void sleep_us(int64_t us) { std::this_thread::sleep_for(std::chrono::microseconds(us)); }
 };
 template <class EvOps, class Clock = SteadyWaitClock> static int wait_event_bounded(typename EvOps::Event ev, int64_t timeout_ms) {
-    const int64_t deadline = Clock::now_us() + (timeout_ms < 0 ? 0 : timeout_ms) * 1000;
+    const int64_t deadline = Clock::now_us() + std::min<int64_t>(timeout_ms < 0 ? 0 : timeout_ms, (int64_t)1 << 40) * 1000;   // (clamped: ~35 years, no overflow)
     int64_t nap = 50;
     for (;;) {
         const int q = EvOps::query(ev);

@@ -64,7 +64,7 @@ def test_a_partner_wait_that_gives_up_is_reported_and_the_grid_drains(monkeypatc
     # with 4 x 24 x 120 frame-iterations x 8 waits per frame some wait misses its first poll in every launch: all three entry points report
     assert all(st == 8 for _, st, _ in statuses), statuses
     assert all(hip == 702 for _, _, hip in statuses), statuses        # hipErrorLaunchTimeOut
-    bad.set_precision(32)                                             # the handle itself is fine: one-wave ... no: N 4096 fp32 streams use s_barrier -- no event waits
+    bad.set_precision(32)                                             # the handle itself is fine (the fp32 kernel's two-wave streams use s_barrier: no event waits to give up)
     got32 = bad.from_mel_batch(mels[:3], None, seeds[:3])
     assert all(np.isfinite(o).all() for o in got32)
     bad.close()

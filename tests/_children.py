@@ -9,7 +9,6 @@ fresh box whose image pages in lazily -- that says nothing about this library, s
 """
 import multiprocessing as mp
 import os
-import queue
 import subprocess
 import sys
 import time
@@ -69,20 +68,21 @@ def _await_warmup():
 
 
 class Reporter:
-    """What a child gets as its first argument: stage(name) and result(value) go to the parent."""
+    """What a child gets as its first argument: stage(name) and result(value) go to the parent -- synchronously, down a pipe (a queue's feeder
+    thread would lose the last reports of a child that dies)."""
 
-    def __init__(self, q, rank=0):
-        self.q, self.rank = q, rank
+    def __init__(self, conn, rank=0):
+        self.conn, self.rank = conn, rank
 
     def stage(self, name):
-        self.q.put(("stage", self.rank, name, time.time()))
+        self.conn.send(("stage", self.rank, name, time.time()))
 
     def result(self, value):
-        self.q.put(("result", self.rank, value, time.time()))
+        self.conn.send(("result", self.rank, value, time.time()))
 
 
-def _child_entry(target, q, rank, args):
-    rep = Reporter(q, rank)
+def _child_entry(target, conn, rank, args):
+    rep = Reporter(conn, rank)
     rep.stage("importing torch")
     try:
         import torch  # noqa: F401  (first: see the module docstring)
@@ -90,21 +90,26 @@ def _child_entry(target, q, rank, args):
         target(rep, *args)
     except BaseException as ex:  # noqa: BLE001
         import traceback
-        q.put(("error", rank, "%r\n%s" % (ex, traceback.format_exc()), time.time()))
+        conn.send(("error", rank, "%r\n%s" % (ex, traceback.format_exc()), time.time()))
         raise
 
 
-def run_children(target, per_rank_args, run_budget_s=RUN_BUDGET_S):
+def run_children(target, per_rank_args, run_budget_s=None):
     """Start one child per entry of `per_rank_args`, each running target(reporter, *args) after importing torch.  Returns the list of
     results by rank.  See the module docstring for what happens to a child that does not finish."""
+    from multiprocessing.connection import wait as wait_conns
+    run_budget_s = RUN_BUDGET_S if run_budget_s is None else run_budget_s
     _await_warmup()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     n = len(per_rank_args)
-    procs = [ctx.Process(target=_child_entry, args=(target, q, r, tuple(a))) for r, a in enumerate(per_rank_args)]
+    pipes = [ctx.Pipe(duplex=False) for _ in range(n)]
+    procs = [ctx.Process(target=_child_entry, args=(target, pipes[r][1], r, tuple(a))) for r, a in enumerate(per_rank_args)]
     t0 = time.time()
     for p in procs:
         p.start()
+    for _, w in pipes:
+        w.close()                                               # the parent's copy of the write end: a dead child then reads as EOF
+    readers = {pipes[r][0]: r for r in range(n)}
     stages = {r: ("started", t0) for r in range(n)}
     results = {}
     failure = None
@@ -113,32 +118,36 @@ def run_children(target, per_rank_args, run_budget_s=RUN_BUDGET_S):
             importing = [r for r in range(n) if r not in results and stages[r][0] in ("started", "importing torch")]
             if importing:
                 deadline, what = t0 + IMPORT_BUDGET_S, "skip"
-            else:                                           # everybody has torch: the clock of the part under test starts at the last import's end
+            else:                                               # everybody has torch: the clock of the part under test runs from the last report
                 deadline, what = max(t for s, t in stages.values()) + run_budget_s, "fail"
-            try:
-                kind, rank, payload, t = q.get(timeout=max(0.2, min(deadline - time.time(), 2.0)))
-            except queue.Empty:
-                names = {r: s for r, (s, _) in stages.items()}
-                if any(p.exitcode not in (None, 0) for p in procs):
-                    failure = ("fail", "a child exited with %s; last stages: %s" % ([p.exitcode for p in procs], names))
-                elif time.time() > deadline and what == "skip":
+            names = {r: s for r, (s, _) in stages.items()}
+            ready = wait_conns(list(readers), timeout=max(0.05, min(deadline - time.time(), 2.0))) if readers else []
+            for c in ready:
+                try:
+                    kind, rank, payload, t = c.recv()
+                except (EOFError, OSError):                     # the child is gone and its pipe is drained
+                    r = readers.pop(c)
+                    procs[r].join(timeout=10)
+                    if r not in results and failure is None:
+                        failure = ("fail", "child %d exited with %s before reporting a result; last stages: %s" % (r, procs[r].exitcode, names))
+                    continue
+                if kind == "stage":
+                    stages[rank] = (payload, time.time())
+                elif kind == "result":
+                    results[rank] = payload
+                elif failure is None:
+                    failure = ("fail", "child %d raised: %s" % (rank, payload))
+            if not ready and failure is None and time.time() > deadline:
+                if what == "skip":
                     failure = ("skip", "`import torch` had not finished in child %s after %.0f s on this box: the torch part of this test was not "
                                        "reached; nothing of libgomel_hip.so was involved" % (importing, time.time() - t0))
-                elif time.time() > deadline:
+                else:
                     failure = ("fail", "child processes exceeded their %.0f s budget after importing torch; last stages: %s" % (run_budget_s, names))
-                continue
-            if kind == "stage":
-                if stages[rank][0] != "torch imported" or payload != "importing torch":
-                    stages[rank] = (payload, t if payload != "torch imported" else time.time())
-            elif kind == "result":
-                results[rank] = payload
-            else:
-                failure = ("fail", "child %d raised: %s" % (rank, payload))
     finally:
         for p in procs:
             p.join(timeout=60 if failure is None else 0.1)
             if p.is_alive():
-                p.kill()                                    # the exact children this call started
+                p.kill()                                        # the exact children this call started
                 p.join()
     if failure is not None:
         (pytest.skip if failure[0] == "skip" else pytest.fail)(failure[1])
@@ -146,5 +155,5 @@ def run_children(target, per_rank_args, run_budget_s=RUN_BUDGET_S):
     return [results[r] for r in range(n)]
 
 
-def run_child(target, args=(), run_budget_s=RUN_BUDGET_S):
+def run_child(target, args=(), run_budget_s=None):
     return run_children(target, [args], run_budget_s)[0]

@@ -27,10 +27,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 os.environ.setdefault("GOMEL_HIP_RUNTIME", "system")
 
 GUARD_DEFAULT_S = float(os.environ.get("GOMEL_TEST_GUARD_S", "240"))
-GUARD_GRACE_S = 30.0
+GUARD_GRACE_S = float(os.environ.get("GOMEL_TEST_GUARD_GRACE_S", "30"))
+
+
+_CONFIG = None
 
 
 def pytest_configure(config):
+    global _CONFIG
+    _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "guard(seconds): wall-clock budget of this test (default %d s)" % GUARD_DEFAULT_S)
     config.addinivalue_line("markers", "torch_child: the test's torch part runs in a child process; collected last")
@@ -124,10 +129,23 @@ class _Guard:
                     self.deadline = time.monotonic() + GUARD_GRACE_S
             if not due:
                 continue
+            # what the guard has to say goes to the REAL stderr: pytest's capture holds fd 2 during a test, and a session that ends through
+            # os._exit would take the captured text with it
+            capman = _CONFIG.pluginmanager.getplugin("capturemanager") if _CONFIG is not None else None
+            if capman is not None:
+                try:
+                    capman.suspend_global_capture(in_=False)
+                except Exception:  # noqa: BLE001 -- diagnostics must not depend on the capture plugin's state
+                    capman = None
             if not fired:
                 sys.stderr.write("\n[test guard] %s exceeded its wall-clock budget; stacks of all threads follow\n" % nodeid)
                 faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 sys.stderr.flush()
+                if capman is not None:
+                    try:
+                        capman.resume_global_capture()
+                    except Exception:  # noqa: BLE001
+                        pass
                 signal.pthread_kill(self.main, signal.SIGALRM)       # fails the test if the interpreter gets control back
             else:
                 sys.stderr.write("\n[test guard] %s: the main thread is still inside native code %d s after the alarm; ending the session "

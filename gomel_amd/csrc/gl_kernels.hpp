@@ -446,16 +446,19 @@ template <bool WIDE> struct StreamFlagSync {
             while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev) {}
 #else
             // The FIRST poll is the unbounded loop's own code -- read, wait, compare, a branch that is not taken when the partner is there -- and
-            // everything about the bound sits behind that branch, out of line: +0.4 ... 0.8 % on k_gl_fused_d<4096,5> against the unbounded
-            // loop.  A bounded loop IN FRONT cost +1.5 % as a two-exit C++ loop (the compiler rebuilds it around exit flags: two more taken
-            // branches per poll), +2.0 % spelled in assembly; an assembly loop behind the first poll +1.4 % (profiles/r06/ab_cap.txt).
+            // everything about the bound sits behind that branch, out of line.  With the give-up store below a GLOBAL store the bound costs
+            // nothing against the unbounded loop (1.2650 against 1.2696 ms on k_gl_fused_d<4096,5>, profiles/r06/ab_stream.txt); while it was a
+            // flat store the same code cost +0.4 ... 0.8 %, a two-exit loop in front +1.5 %, assembly spellings +1.4 ... 2.0 % (ab_cap.txt).
             if (__builtin_expect(__builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) < ev, 0)) {
                 unsigned polls = 0;
                 bool there;
                 do { there = __builtin_amdgcn_readfirstlane(*(volatile lds_u32*)other) >= ev; } while (!there && ++polls <= cap);
                 if (!there) {                                 // ran out of polls: the partner wave has stopped
                     cap = 0;
-                    if (err) *(volatile unsigned*)err = 1u;   // (every lane stores the same word: no divergent branch)
+                    // (every lane stores the same word: no divergent branch.  A GLOBAL store, not a flat one through the generic pointer:
+                    // a flat access counts on lgkmcnt as well, and one pending at the join behind this branch -- taken or not -- made the
+                    // compiler turn every counted LDS wait that follows a poll into lgkmcnt(0): that, not the loop, was the bound's cost)
+                    if (err) *(volatile __attribute__((address_space(1))) unsigned*)err = 1u;
                 }
             }
 #endif
@@ -2222,4 +2225,3 @@ __global__ __launch_bounds__(128) void k_irfft(const float* __restrict__ spec, f
         for (int j = 0; j < 16; j++) ys[t + G::T * j] = v[j];
     }
 }
-

@@ -140,7 +140,7 @@ GL_DEV void wait_both(StreamFlagSync<true>& a, StreamFlagSync<true>& b) {
         if ((ra >= a.ev) & (rb >= b.ev)) break;                                                            // at the loop's exit costs an lgkmcnt(0) at the next use of its register
         if (__builtin_expect(++polls > a.cap, 0)) {
             a.cap = 0;
-            if (a.err && (threadIdx.x & 63) == 0) *(volatile unsigned*)a.err = 1u;
+            if (a.err) *(volatile __attribute__((address_space(1))) unsigned*)a.err = 1u;   // (a GLOBAL store: a flat one pending at the join poisons every counted LDS wait behind the poll)
             break;
         }
     }

@@ -1450,9 +1450,14 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
             // what is left (N - hop samples) lies past the owned range: the next segment's head (tail buffer) or the utterance's end
             v2f* dst = d.has_next ? tout : xout_p + owned2;
             float* dstf = d.has_next ? tout_f : xout_f + d.G * hop;
+            // (the lane index is laundered so that these sixteen addresses are formed HERE, once per segment: hoisted out of the frame loop as
+            // 64-bit values they did not fit the 256 registers of a two-waves-per-SIMD kernel, were spilled, and every store below reloaded its
+            // address from scratch behind a vmcnt(0) -- 10 to 28 such reloads per segment in the N 2048 / 4096 builds)
+            int tl = t;
+            asm volatile("" : "+v"(tl));
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const int i = t + T * j;
+                const int i = tl + T * j;
                 if constexpr (ODD) {
                     if (2 * i + 1 < keepf) *reinterpret_cast<v2f_a4*>(dstf + 2 * i) = acc[j];
                     else if (2 * i < keepf) dstf[2 * i] = acc[j].x;

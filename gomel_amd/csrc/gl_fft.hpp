@@ -379,8 +379,16 @@ template <int NV, int NW> GL_DEV void sgb_valu_then_write() {   // NW times: NV 
 // Then layout A uses ONE row stride in both directions (SAI: the inverse's transposed write stays conflict-free, the forward's transposed
 // read takes a two-way conflict on one lane pair per group), the inverse's last reads and the next forward's first writes are again
 // same-lane-same-slot, and the synchronisation between THEM goes too.
+// PAIRED bit 2 (round 6; geometries with one butterfly per lane and pass: N 4096): the pass-2 butterfly's results go back to the SLOTS ITS OPERANDS CAME
+// FROM -- element (q1, t2, q2) at row q1, column t2 + 8 q2 of layout A -- instead of into layout B.  Every slot then has exactly one owner lane in
+// every pass (the lane that reads it is the lane that overwrites it), so the whole frame needs no "the partner has read, I may write" synchronisation:
+// what is left is one "the partner has written, I may read" per exchange (4 polls per frame instead of 6, no event published behind a read burst).
+// Pass 3 finds the eight operands of butterfly b = q1 + R1 q2 in eight CONSECUTIVE slots of row q1 (conflict-free across a 16-lane group for the odd
+// row stride SAI); layout B is not used.  Arithmetic and its order are unchanged: bit-identical results.
 template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
-    constexpr int SA = (PAIRED & 2) ? G::SAI : G::SA;
+    constexpr bool INPL = (PAIRED & 4) && G::NB1 == 1 && G::NB2 == 1;
+    static_assert(!(PAIRED & 4) || INPL, "the in-place exchange is built for one butterfly per lane and pass");
+    constexpr int SA = ((PAIRED & 2) || INPL) ? G::SAI : G::SA;
     // ---- pass 1: NB1 radix-R1 butterflies; butterfly u holds registers j = u + NB1*m, t1 = t + T*u
     // The pass's twiddles are read into registers BEFORE any exchange store: table and exchange area live in the same
     // LDS array, so a twiddle read placed after a store could not be hoisted above it (one LDS round trip per element).
@@ -427,7 +435,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
 #pragma unroll
         for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * SA + t2 + 8 * m];
     }
-    sync_reads_done(sync);
+    if constexpr (!INPL) sync_reads_done(sync);
     st.mark(2);
     V w2[16];
 #pragma unroll
@@ -441,14 +449,15 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ILV) {
         st.mark(3);
-        sync_before_write(sync);
+        if constexpr (!INPL) sync_before_write(sync);
 #pragma unroll
         for (int u = 0; u < G::NB2; u++) {
             const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
 #pragma unroll
             for (int q = 0; q < G::R2; q++) {
                 if (q) v[u * G::R2 + q] = cmul(v[u * G::R2 + q], w2[u * G::R2 + q]);
-                lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
+                if constexpr (INPL) lds[q1 * SA + t2 + 8 * q] = v[u * G::R2 + q];
+                else lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
             }
         }
         sgb_valu_then_write<4, 16>();
@@ -456,20 +465,29 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) apply_tw<false, 1, G::R2>(&v[u * G::R2], &w2[u * G::R2]);
     st.mark(3);
-    sync_before_write(sync);
+    if constexpr (!INPL) sync_before_write(sync);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
 #pragma unroll
-        for (int q = 0; q < G::R2; q++) lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
+        for (int q = 0; q < G::R2; q++) {
+            if constexpr (INPL) lds[q1 * SA + t2 + 8 * q] = v[u * G::R2 + q];
+            else lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
+        }
     }
     }
     sync();
     st.mark(4);
     // ---- pass 3: the mirrored radix-8 butterflies bA, bB
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
+    if constexpr (INPL) {   // butterfly b = q1 + R1 q2: its operands t2 = 0 .. 7 sit side by side in row q1
+        const int oA = (bA % G::R1) * SA + 8 * (bA / G::R1), oB = (bB % G::R1) * SA + 8 * (bB / G::R1);
+#pragma unroll
+        for (int r = 0; r < 8; r++) { v[r] = lds[oA + r]; v[8 + r] = lds[oB + r]; }
+    } else {
 #pragma unroll
     for (int r = 0; r < 8; r++) { v[r] = lds[r * G::SB + bA]; v[8 + r] = lds[r * G::SB + bB]; }
+    }
     if constexpr (!(PAIRED & 1)) sync_reads_done(sync);
     st.mark(5);
     dft8<false, 1>(&v[0]);
@@ -484,15 +502,20 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
 // kernel whose next step is a forward FFT can hand them to it instead of reading the table again.
 template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void fft_inverse(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st, V* w1_out = nullptr) {
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
+    constexpr bool INPL = (PAIRED & 4) && G::NB1 == 1 && G::NB2 == 1;   // (fft_forward)
+    static_assert(!(PAIRED & 4) || INPL, "the in-place exchange is built for one butterfly per lane and pass");
+    // pass 3's slots: layout B, or (INPL) eight consecutive slots of row q1 of layout A
+    const int oA = INPL ? (bA % G::R1) * G::SAI + 8 * (bA / G::R1) : bA, oB = INPL ? (bB % G::R1) * G::SAI + 8 * (bB / G::R1) : bB;
+    constexpr int S3 = INPL ? 1 : G::SB;
     constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
     if constexpr (ILV) {   // the first butterfly's eight outputs leave while the second one computes
         if constexpr (!(PAIRED & 1)) sync_before_write(sync);
         dft8<true, 1>(&v[0]);
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds[r * G::SB + bA] = v[r];
+        for (int r = 0; r < 8; r++) lds[r * S3 + oA] = v[r];
         dft8<true, 1>(&v[8]);
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds[r * G::SB + bB] = v[8 + r];
+        for (int r = 0; r < 8; r++) lds[r * S3 + oB] = v[8 + r];
         __builtin_amdgcn_sched_group_barrier(GL_SGB_VALU, 56, 0);
         sgb_valu_then_write<7, 8>();
         sgb_valu_then_write<0, 8>();
@@ -502,7 +525,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     st.mark(8);
     if constexpr (!(PAIRED & 1)) sync_before_write(sync);
 #pragma unroll
-    for (int r = 0; r < 8; r++) { lds[r * G::SB + bA] = v[r]; lds[r * G::SB + bB] = v[8 + r]; }
+    for (int r = 0; r < 8; r++) { lds[r * S3 + oA] = v[r]; lds[r * S3 + oB] = v[8 + r]; }
     }
     sync();
     st.mark(9);
@@ -512,18 +535,19 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
         V w2[16];
 #pragma unroll
         for (int q = 0; q < G::R2; q++) {
-            v[u * G::R2 + q] = lds[t2 * G::SB + q1 + G::R1 * q];
+            if constexpr (INPL) v[u * G::R2 + q] = lds[q1 * G::SAI + t2 + 8 * q];
+            else v[u * G::R2 + q] = lds[t2 * G::SB + q1 + G::R1 * q];
             if (q) w2[q] = tw.w2r ? tw.w2r[u * G::R2 + q] : tw.tw2[q * 8 + t2];
         }
         apply_tw<true, 1, G::R2>(&v[u * G::R2], w2);
     }
-    sync_reads_done(sync);
+    if constexpr (!INPL) sync_reads_done(sync);
     st.mark(10);
 #pragma unroll
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
         dftR<true, G::R2, 1>(&v[u * G::R2]);
-        if (u == 0) sync_before_write(sync);
+        if constexpr (!INPL) { if (u == 0) sync_before_write(sync); }
 #pragma unroll
         for (int m = 0; m < G::R2; m++) lds[q1 * G::SAI + t2 + 8 * m] = v[u * G::R2 + m];
     }

@@ -30,6 +30,12 @@ static_assert(glbig::kMaxN == kBigMaxN, "gl_types.hpp and gl_big.hpp agree on th
 #ifndef GL_D_PAIRED
 #define GL_D_PAIRED 3    // fp64 fused and persistent kernels (the generic and any-hop kernels take bit 0 only)
 #endif
+// Bit 2 (round 6): the in-place pass-2 exchange (gl_fft.hpp) wherever the geometry has one butterfly per lane and pass (N 4096) -- no "partner has
+// read" synchronisation left in a frame.  GL_D_INPLACE=0 builds the two-layout form (A/B).
+#ifndef GL_D_INPLACE
+#define GL_D_INPLACE 1
+#endif
+template <class G> constexpr int d_paired() { return GL_D_PAIRED | ((GL_D_INPLACE && GL_D_PAIRED == 3 && G::NB1 == 1 && G::NB2 == 1) ? 4 : 0); }
 
 // =============================================================================================== device tables
 struct DevTables {
@@ -939,10 +945,10 @@ __global__ __launch_bounds__(128, 1) void k_gl_persist_d(const double* __restric
         load_wn<G>(wn, tl, tb.wnd);
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] *= w2[tl + T * j];
-        fft_forward<G, GL_D_PAIRED>(v, my, tl, tw, sync);
+        fft_forward<G, d_paired<G>()>(v, my, tl, tw, sync);
         spectral_apply<G>(v, t, mr, wn);
         asm volatile("" : "+v"(tl));
-        fft_inverse<G, GL_D_PAIRED>(v, my, tl, tw, sync);
+        fft_inverse<G, d_paired<G>()>(v, my, tl, tw, sync);
         asm volatile("" : "+v"(tl));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sentinel stores are through before any fresh pair goes out
 #pragma unroll
@@ -1636,9 +1642,9 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
         st.mark(15);   // (window reads + multiply, slide, next rows' loads issued)
         if constexpr (W1CARRY) {
             const Twiddles<v2d> twf{tw1_l, tw2_l, nullptr, w1c, G::R1 - 1, nullptr};
-            fft_forward<G, GL_D_PAIRED>(v, my, t, twf, sync, st);
+            fft_forward<G, d_paired<G>()>(v, my, t, twf, sync, st);
         } else {
-            fft_forward<G, GL_D_PAIRED>(v, my, t, tw, sync, st);
+            fft_forward<G, d_paired<G>()>(v, my, t, tw, sync, st);
         }
         {
             MagRegsD mr;
@@ -1650,7 +1656,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_d(const double* _
             spectral_apply<G>(v, t, mr, wn);
         }
         st.mark(7);
-        fft_inverse<G, GL_D_PAIRED>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
+        fft_inverse<G, d_paired<G>()>(v, my, t, tw, sync, st, W1CARRY ? w1c : nullptr);
 #pragma unroll
         for (int jj = 0; jj < SH; jj++) xin[KEEP + jj] = xl[jj];
         if (any_next) {

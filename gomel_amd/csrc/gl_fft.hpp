@@ -385,6 +385,20 @@ template <int NV, int NW> GL_DEV void sgb_valu_then_write() {   // NW times: NV 
 // what is left is one "the partner has written, I may read" per exchange (4 polls per frame instead of 6, no event published behind a read burst).
 // Pass 3 finds the eight operands of butterfly b = q1 + R1 q2 in eight CONSECUTIVE slots of row q1 (conflict-free across a 16-lane group for the odd
 // row stride SAI); layout B is not used.  Arithmetic and its order are unchanged: bit-identical results.
+// (A/B knobs, profiles/r06/ab_inplace.txt: the odd stride SAI = 129 is the best of 129 / 130 / either with a column swizzle -- 1.2566 / 1.2718 / 1.2701 /
+// 1.3127 ms; with ONE stride for the transposed reads AND writes one of the two conflicts two-way, and the writes' conflicts cost more.  The counters show it:
+// SQ_LDS_BANK_CONFLICT 39 M per launch against 13 M for the two-layout form -- the in-place exchange wins by what it no longer waits for, not by its LDS pattern)
+#ifndef GL_D_INPL_SA
+#define GL_D_INPL_SA 0      // row stride of the in-place layout in slots (0: G::SAI)
+#endif
+#ifndef GL_D_INPL_XOR
+#define GL_D_INPL_XOR 0     // 1: column ^ ((row >> 2) & 1)
+#endif
+// slot of (row q, column c) of the in-place layout
+template <class G> GL_DEV int inpl_slot(int q, int c) {
+    constexpr int S = GL_D_INPL_SA ? GL_D_INPL_SA : G::SAI;
+    return q * S + (GL_D_INPL_XOR ? (c ^ ((q >> 2) & 1)) : c);
+}
 template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void fft_forward(V (&v)[16], V* lds, int t, const Twiddles<V>& tw, SyncT sync, St& st) {
     constexpr bool INPL = (PAIRED & 4) && G::NB1 == 1 && G::NB2 == 1;
     static_assert(!(PAIRED & 4) || INPL, "the in-place exchange is built for one butterfly per lane and pass");
@@ -410,7 +424,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
 #pragma unroll
             for (int q = 0; q < G::R1; q++) {
                 if (q) v[u + G::NB1 * q] = cmul(v[u + G::NB1 * q], w1[u + G::NB1 * q]);
-                lds[q * SA + t1] = v[u + G::NB1 * q];
+                if constexpr (INPL) lds[inpl_slot<G>(q, t1)] = v[u + G::NB1 * q]; else lds[q * SA + t1] = v[u + G::NB1 * q];
             }
         }
         sgb_valu_then_write<4, 16>();
@@ -423,7 +437,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     for (int u = 0; u < G::NB1; u++) {
         const int t1 = t + G::T * u;
 #pragma unroll
-        for (int q = 0; q < G::R1; q++) lds[q * SA + t1] = v[u + G::NB1 * q];
+        for (int q = 0; q < G::R1; q++) { if constexpr (INPL) lds[inpl_slot<G>(q, t1)] = v[u + G::NB1 * q]; else lds[q * SA + t1] = v[u + G::NB1 * q]; }
     }
     }
     sync();
@@ -433,7 +447,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     for (int u = 0; u < G::NB2; u++) {
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
 #pragma unroll
-        for (int m = 0; m < G::R2; m++) v[u * G::R2 + m] = lds[q1 * SA + t2 + 8 * m];
+        for (int m = 0; m < G::R2; m++) { if constexpr (INPL) v[u * G::R2 + m] = lds[inpl_slot<G>(q1, t2 + 8 * m)]; else v[u * G::R2 + m] = lds[q1 * SA + t2 + 8 * m]; }
     }
     if constexpr (!INPL) sync_reads_done(sync);
     st.mark(2);
@@ -456,7 +470,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
 #pragma unroll
             for (int q = 0; q < G::R2; q++) {
                 if (q) v[u * G::R2 + q] = cmul(v[u * G::R2 + q], w2[u * G::R2 + q]);
-                if constexpr (INPL) lds[q1 * SA + t2 + 8 * q] = v[u * G::R2 + q];
+                if constexpr (INPL) lds[inpl_slot<G>(q1, t2 + 8 * q)] = v[u * G::R2 + q];
                 else lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
             }
         }
@@ -471,7 +485,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
         const int beta = t + G::T * u, q1 = beta % G::R1, t2 = beta / G::R1;
 #pragma unroll
         for (int q = 0; q < G::R2; q++) {
-            if constexpr (INPL) lds[q1 * SA + t2 + 8 * q] = v[u * G::R2 + q];
+            if constexpr (INPL) lds[inpl_slot<G>(q1, t2 + 8 * q)] = v[u * G::R2 + q];
             else lds[t2 * G::SB + q1 + G::R1 * q] = v[u * G::R2 + q];
         }
     }
@@ -481,9 +495,8 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     // ---- pass 3: the mirrored radix-8 butterflies bA, bB
     const int bA = t, bB = t ? G::B3 - t : G::B3 / 2;
     if constexpr (INPL) {   // butterfly b = q1 + R1 q2: its operands t2 = 0 .. 7 sit side by side in row q1
-        const int oA = (bA % G::R1) * SA + 8 * (bA / G::R1), oB = (bB % G::R1) * SA + 8 * (bB / G::R1);
 #pragma unroll
-        for (int r = 0; r < 8; r++) { v[r] = lds[oA + r]; v[8 + r] = lds[oB + r]; }
+        for (int r = 0; r < 8; r++) { v[r] = lds[inpl_slot<G>(bA % G::R1, 8 * (bA / G::R1) + r)]; v[8 + r] = lds[inpl_slot<G>(bB % G::R1, 8 * (bB / G::R1) + r)]; }
     } else {
 #pragma unroll
     for (int r = 0; r < 8; r++) { v[r] = lds[r * G::SB + bA]; v[8 + r] = lds[r * G::SB + bB]; }
@@ -505,17 +518,16 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     constexpr bool INPL = (PAIRED & 4) && G::NB1 == 1 && G::NB2 == 1;   // (fft_forward)
     static_assert(!(PAIRED & 4) || INPL, "the in-place exchange is built for one butterfly per lane and pass");
     // pass 3's slots: layout B, or (INPL) eight consecutive slots of row q1 of layout A
-    const int oA = INPL ? (bA % G::R1) * G::SAI + 8 * (bA / G::R1) : bA, oB = INPL ? (bB % G::R1) * G::SAI + 8 * (bB / G::R1) : bB;
-    constexpr int S3 = INPL ? 1 : G::SB;
+    auto s3 = [&](int b, int r) { if constexpr (INPL) return inpl_slot<G>(b % G::R1, 8 * (b / G::R1) + r); else return r * G::SB + b; };
     constexpr bool ILV = GL_D_INTERLEAVE && __is_same(V, v2d) && IsSplitSync<SyncT>::value;
     if constexpr (ILV) {   // the first butterfly's eight outputs leave while the second one computes
         if constexpr (!(PAIRED & 1)) sync_before_write(sync);
         dft8<true, 1>(&v[0]);
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds[r * S3 + oA] = v[r];
+        for (int r = 0; r < 8; r++) lds[s3(bA, r)] = v[r];
         dft8<true, 1>(&v[8]);
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds[r * S3 + oB] = v[8 + r];
+        for (int r = 0; r < 8; r++) lds[s3(bB, r)] = v[8 + r];
         __builtin_amdgcn_sched_group_barrier(GL_SGB_VALU, 56, 0);
         sgb_valu_then_write<7, 8>();
         sgb_valu_then_write<0, 8>();
@@ -525,7 +537,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
     st.mark(8);
     if constexpr (!(PAIRED & 1)) sync_before_write(sync);
 #pragma unroll
-    for (int r = 0; r < 8; r++) { lds[r * S3 + oA] = v[r]; lds[r * S3 + oB] = v[8 + r]; }
+    for (int r = 0; r < 8; r++) { lds[s3(bA, r)] = v[r]; lds[s3(bB, r)] = v[8 + r]; }
     }
     sync();
     st.mark(9);
@@ -535,7 +547,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
         V w2[16];
 #pragma unroll
         for (int q = 0; q < G::R2; q++) {
-            if constexpr (INPL) v[u * G::R2 + q] = lds[q1 * G::SAI + t2 + 8 * q];
+            if constexpr (INPL) v[u * G::R2 + q] = lds[inpl_slot<G>(q1, t2 + 8 * q)];
             else v[u * G::R2 + q] = lds[t2 * G::SB + q1 + G::R1 * q];
             if (q) w2[q] = tw.w2r ? tw.w2r[u * G::R2 + q] : tw.tw2[q * 8 + t2];
         }
@@ -549,7 +561,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
         dftR<true, G::R2, 1>(&v[u * G::R2]);
         if constexpr (!INPL) { if (u == 0) sync_before_write(sync); }
 #pragma unroll
-        for (int m = 0; m < G::R2; m++) lds[q1 * G::SAI + t2 + 8 * m] = v[u * G::R2 + m];
+        for (int m = 0; m < G::R2; m++) { if constexpr (INPL) lds[inpl_slot<G>(q1, t2 + 8 * m)] = v[u * G::R2 + m]; else lds[q1 * G::SAI + t2 + 8 * m] = v[u * G::R2 + m]; }
     }
     sync();
     st.mark(11);
@@ -559,7 +571,7 @@ template <class G, int PAIRED = 0, class V, class SyncT, class St> GL_DEV void f
         V w1[16];
 #pragma unroll
         for (int q = 0; q < G::R1; q++) {
-            v[u + G::NB1 * q] = lds[q * G::SAI + t1];
+            if constexpr (INPL) v[u + G::NB1 * q] = lds[inpl_slot<G>(q, t1)]; else v[u + G::NB1 * q] = lds[q * G::SAI + t1];
             if (q) w1[G::NB1 * q] = (tw.w1r && q <= tw.w1r_n) ? tw.w1r[u + G::NB1 * q] : tw.tw1[q * G::C1 + t1];
             if (q && w1_out) w1_out[u + G::NB1 * q] = w1[G::NB1 * q];
         }

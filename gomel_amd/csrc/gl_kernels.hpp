@@ -35,6 +35,10 @@ static_assert(glbig::kMaxN == kBigMaxN, "gl_types.hpp and gl_big.hpp agree on th
 #ifndef GL_D_INPLACE
 #define GL_D_INPLACE 1
 #endif
+#ifndef GL_INPLACE
+#define GL_INPLACE 0     // the same for the fp32 fused / persistent kernels (experiment: 8-byte slots conflict two-way in pass 3)
+#endif
+template <class G> constexpr int f_paired() { return GL_PAIRED | ((GL_INPLACE && G::NB1 == 1 && G::NB2 == 1) ? 4 : 0); }
 template <class G> constexpr int d_paired() { return GL_D_PAIRED | ((GL_D_INPLACE && GL_D_PAIRED == 3 && G::NB1 == 1 && G::NB2 == 1) ? 4 : 0); }
 
 // =============================================================================================== device tables
@@ -768,13 +772,13 @@ __global__ __launch_bounds__(128, OCC) void k_gl_persist(const float* __restrict
             load_mags_raw<G>(mraw, tl, mag + frame * G::C, nyq + frame);
             load_wn<G>(wn, tl, tb.wn);
         }
-        fft_forward<G, GL_PAIRED>(v, my, tl, tw, sync);
+        fft_forward<G, f_paired<G>()>(v, my, tl, tw, sync);
         st.mark(3);
         if constexpr (LEAN) finish_mags(mr, mraw, t == 0);
         spectral_apply<G>(v, t, mr, wn);
         st.mark(4);
         if constexpr (LEAN) asm volatile("" : "+v"(tl));
-        fft_inverse<G, GL_PAIRED>(v, my, tl, tw, sync);
+        fft_inverse<G, f_paired<G>()>(v, my, tl, tw, sync);
         st.mark(5);
         if constexpr (LEAN) {
             asm volatile("" : "+v"(tl));
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         };
         if constexpr (!fused_late_rows(N)) issue_rows();
         st.mark(15);
-        fft_forward<G, GL_PAIRED>(v, my, t, tw, sync, st);
+        fft_forward<G, f_paired<G>()>(v, my, t, tw, sync, st);
         {
             MagRegs mr;
             finish_mags(mr, mraw, t == 0);
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused(const float* __re
         }
         st.mark(7);
         if constexpr (fused_late_rows(N)) issue_rows();
-        fft_inverse<G, GL_PAIRED>(v, my, t, tw, sync, st);
+        fft_inverse<G, f_paired<G>()>(v, my, t, tw, sync, st);
         // The next frame's rows: unpacked BEFORE this frame's stores are issued.  vmcnt counts loads and stores in issue order,
         // so a wait placed behind the (conditional) stores below would have to drain them too -- a full store round trip at the
         // end of every frame; here only loads issued a frame's worth of cycles ago are pending.

@@ -102,7 +102,7 @@ type engine struct {
 
 const maxEngines = 8
 
-// JobTimeout bounds FromMelBatch's wait for the device (gomel_job_wait_timeout); a call still running then returns ErrBusy.
+// JobTimeout bounds FromMelBatch's wait for the device when WholeBatchCalls is set (gomel_job_wait_timeout); a call still running then returns ErrBusy.
 var JobTimeout = 10 * time.Minute
 
 var (
@@ -350,24 +350,31 @@ func (m *Mel) FromMelBatch(spectra [][][2]float64) ([][]float64, error) {
 		outs[u] = (*C.double)(unsafe.Pointer(&res[u][0]))
 		lens[u] = C.size_t(len(sp))
 	}
-	// submit + bounded waits: a goroutine never blocks without end behind a device that has stopped answering.  A job that outlives
-	// JobTimeout is reported as ErrBusy and waited for in the background (it still owns the pinned slices: they stay pinned until it ends).
-	var job *C.gomel_job
-	rc := C.gomel_from_mel_batch_submit(e.h, C.size_t(n), &mels[0], &lens[0], &x0s[0], nil, &outs[0], nil, &job)
-	if rc == C.GOMEL_OK {
-		rc = C.gomel_job_wait_timeout(job, C.int64_t(JobTimeout/time.Millisecond))
-		if rc == C.GOMEL_ERR_BUSY {
-			held := pin
-			pin = runtime.Pinner{}
-			enginesMu.Lock()
-			e.refs++ // the background wait's own reference (the deferred release() balances this call's)
-			enginesMu.Unlock()
-			go func() {
-				C.gomel_job_wait(job)
-				held.Unpin()
-				e.release()
-			}()
-			return nil, ErrBusy
+	var rc C.int
+	if !WholeBatchCalls {
+		// a lone caller: the chunked synchronous call (its copies hidden behind its own kernels: the best one call at a time gets)
+		rc = C.gomel_from_mel_batch(e.h, C.size_t(n), &mels[0], &lens[0], &x0s[0], nil, &outs[0], nil)
+	} else {
+		// pipelined callers (the handle is in whole-batch call mode): submit + a BOUNDED wait -- a goroutine never blocks without end behind a
+		// device that has stopped answering.  A job that outlives JobTimeout is reported as ErrBusy and waited for in the background (it
+		// still owns the pinned slices: they stay pinned until it ends).  Same launches, same bits as the synchronous call in this mode.
+		var job *C.gomel_job
+		rc = C.gomel_from_mel_batch_submit(e.h, C.size_t(n), &mels[0], &lens[0], &x0s[0], nil, &outs[0], nil, &job)
+		if rc == C.GOMEL_OK {
+			rc = C.gomel_job_wait_timeout(job, C.int64_t(JobTimeout/time.Millisecond))
+			if rc == C.GOMEL_ERR_BUSY {
+				held := pin
+				pin = runtime.Pinner{}
+				enginesMu.Lock()
+				e.refs++ // the background wait's own reference (the deferred release() balances this call's)
+				enginesMu.Unlock()
+				go func() {
+					C.gomel_job_wait(job)
+					held.Unpin()
+					e.release()
+				}()
+				return nil, ErrBusy
+			}
 		}
 	}
 	for _, sp := range spectra {

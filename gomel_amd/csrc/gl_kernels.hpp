@@ -39,6 +39,10 @@ static_assert(glbig::kMaxN == kBigMaxN, "gl_types.hpp and gl_big.hpp agree on th
 #define GL_INPLACE 0     // the same for the fp32 fused / persistent kernels (experiment: 8-byte slots conflict two-way in pass 3)
 #endif
 template <class G> constexpr int f_paired() { return GL_PAIRED | ((GL_INPLACE && G::NB1 == 1 && G::NB2 == 1) ? 4 : 0); }
+#ifndef GL_D_INPLACE_ANY
+#define GL_D_INPLACE_ANY 0   // ... and for the fp64 generic / any-hop kernels (pass-3 joint paired only: bit 0 | bit 2)
+#endif
+template <class G> constexpr int g_paired_d() { return (GL_PAIRED & 1) | ((GL_D_INPLACE_ANY && G::NB1 == 1 && G::NB2 == 1) ? 4 : 0); }
 template <class G> constexpr int d_paired() { return GL_D_PAIRED | ((GL_D_INPLACE && GL_D_PAIRED == 3 && G::NB1 == 1 && G::NB2 == 1) ? 4 : 0); }
 
 // =============================================================================================== device tables
@@ -349,9 +353,9 @@ __global__ __launch_bounds__(128, GL_FRAMES_D_WAVES) void k_gl_frames_d(const do
     load_wn<G>(wn, t, tb.wnd);
 #pragma unroll
     for (int j = 0; j < 16; j++) v[j] = xs[t + G::T * j] * w2[t + G::T * j];
-    fft_forward<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
+    fft_forward<G, g_paired_d<G>()>(v, my, t, tw, sync);
     spectral_apply<G>(v, t, mr, wn);
-    fft_inverse<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
+    fft_inverse<G, g_paired_d<G>()>(v, my, t, tw, sync);
     if (live) {
         v2d* ys = reinterpret_cast<v2d*>(yw + frame * N);
 #pragma unroll
@@ -1826,7 +1830,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
             }
         }
         sync_reads_done(sync);   // the exchange area goes to the FFT now (its first write burst waits: sync_before_write)
-        fft_forward<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
+        fft_forward<G, g_paired_d<G>()>(v, my, t, tw, sync);
         {
             MagRegsD mr;
             finish_mags_d(mr, mraw, t == 0);
@@ -1836,7 +1840,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void k_gl_fused_any_d(const doubl
             }
             spectral_apply<G>(v, t, mr, wn);
         }
-        fft_inverse<G, (GL_PAIRED & 1)>(v, my, t, tw, sync);
+        fft_inverse<G, g_paired_d<G>()>(v, my, t, tw, sync);
 #pragma unroll
         for (int j = 0; j < 16; j++) asm volatile("" : "+v"(xin[j]));   // the new samples are taken in BEFORE this frame's stores are issued
         __builtin_amdgcn_sched_barrier(0);

@@ -64,7 +64,9 @@ def test_kernels_that_keep_their_exchange_area_to_themselves_use_the_paired_form
     # geometry has one butterfly per lane and pass and the knob is on: fp64 yes, fp32 no)
     assert k.count("fft_forward<G, d_paired<G>()>") == 3 and k.count("fft_inverse<G, d_paired<G>()>") == 2      # k_gl_fused_d (two twiddle forms of the forward call), k_gl_persist_d
     assert k.count("fft_forward<G, f_paired<G>()>") == 2 and k.count("fft_inverse<G, f_paired<G>()>") == 2      # k_gl_fused, k_gl_persist
-    assert k.count("fft_forward<G, (GL_PAIRED & 1)>") == 4 and k.count("fft_inverse<G, (GL_PAIRED & 1)>") == 4   # pass-3 joint only: k_gl_frames[_d], k_gl_fused_any[_d]
+    assert k.count("fft_forward<G, (GL_PAIRED & 1)>") == 2 and k.count("fft_inverse<G, (GL_PAIRED & 1)>") == 2   # pass-3 joint only: k_gl_frames, k_gl_fused_any
+    assert k.count("fft_forward<G, g_paired_d<G>()>") == 2 and k.count("fft_inverse<G, g_paired_d<G>()>") == 2   # ... and their fp64 forms (bit 2 measured there: slower, GL_D_INPLACE_ANY 0)
+    assert "#define GL_D_INPLACE_ANY 0" in k
     assert len(re.findall(r"fft_(forward|inverse)<G, [^>]+>", k)) == 17
 
 

@@ -610,7 +610,7 @@ def main():
                      "algorithmic_flops_per_launch": flops_launch, "flops_convention": "SURVEY 8(d): 2 * 2.5 N log2 N (real-FFT pair) + 8 N per frame-iteration; peak = the %s VECTOR peak (no matrix cores: FFT butterflies)" % ktype,
                      "valu_issue_utilisation": None if not issue else issue.get("valu_issue_frac"),
                      "counters": issue, "counters_source": None if not issue else "profiles/issue.json [%s] (separate rocprofv3 --pmc passes, not this run)" % issue.get("from", "?")}
-        bound_of = {"k_gl_fused_d": "vector issue (1 wave/SIMD: 376 registers, 152 KB LDS; nothing overlaps the LDS round trips)",
+        bound_of = {"k_gl_fused_d": "vector issue (1 wave/SIMD: 374 registers, 152 KB LDS; nothing overlaps the LDS round trips)",
                     "k_gl_fused": "vector issue + power (2 waves/SIMD, VALU ~70 % busy)", "k_gl_persist": "latency of the inter-workgroup exchange"}
         for kname, kv in kernels.items():
             kv["bound"] = bound_of.get(kname, "hbm")

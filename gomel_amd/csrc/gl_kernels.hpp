@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(kFusedThreads, 2) void k_gl_fused_any(const float* 
 // The same sliding-window kernel in double precision: what makes 64-bit mode (the only mode that agrees with the reference's fp64
 // arithmetic on EVERY input) affordable.  Same segments, same ownership / tail rule, same lane-slot magnitude
 // rows (double), same FFT core (its C++ forms: the packed-math asm blocks are fp32-only).  Differences forced by the type: one
-// wave per SIMD (launch_bounds(256, 1): 376 registers, 120 of them AGPRs -- 16 complex doubles of frame data, 16 of input window, the
+// wave per SIMD (launch_bounds(256, 1): 374 registers, 118 of them AGPRs -- 16 complex doubles of frame data, 16 of input window, the
 // accumulator, magnitudes, twiddles), all LDS dynamic (152 KB at N 4096: exchange areas + TW1 + TW2 + window + W_N^k in double), a lane's sample pair
 // is already 16 bytes (plain dwordx4 loads / stores, no DPP row pairing).  Algorithmic bytes per frame-iteration: twice the fp32
 // kernel's.  The fp64 vector unit runs at half the fp32 rate and packs nothing, so expect ~2.3x the fp32 time.

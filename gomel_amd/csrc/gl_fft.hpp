@@ -845,7 +845,16 @@ GL_DEV double rsqrt_d(double p) {
     const double c = __builtin_fma(e, 0.375, 0.5);
     return __builtin_fma(y, c * e, y);
 }
-GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
+// GL_D_CLAMP_PATCH: the rare scaled form of the phasor as a patch BEHIND the common form (one branch per bin pair) instead of an if / else around both (two branches
+// and a flag per pair in the compiled code: 34 scalar instructions and 8 branches more per frame).  Bit-identical; k_gl_fused_d<4096,5> -0.4 ... -0.7 % (n = 8 and 12,
+// one box each), +1.5 % at N 1024 (n = 6), the persistent kernel +-0: taken from N 4096 on.  profiles/r06/ab_clamp_patch.txt
+#ifndef GL_D_CLAMP_PATCH
+#define GL_D_CLAMP_PATCH 1
+#endif
+#ifndef GL_D_CLAMP_PATCH_MINN
+#define GL_D_CLAMP_PATCH_MINN 4096
+#endif
+template <bool PATCH> GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     v2d bc = v2d{b.x, -b.y};
     v2d p = a + bc, d = a - bc;
     v2d q = cmul(w, rot_mi(d));
@@ -854,6 +863,21 @@ GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     // (the reference: phase 0, Y = M) or whose square is not a positive normal number takes the scaled form -- rare, wave-uniform branch
     const double pk = __builtin_fma(xk.x, xk.x, xk.y * xk.y), pc = __builtin_fma(xc.x, xc.x, xc.y * xc.y);
     v2d e, f;
+    if constexpr (PATCH) {
+    // the common form unconditionally, the scaled form as a PATCH behind it: compiles to ONE branch per pair, where the if / else spelling below
+    // compiles to two branches and a flag
+    {
+        const double fk = rsqrt_d(pk) * ma, fc = rsqrt_d(pc) * mb;
+        const v2d vv = xc * fc, kk = v2d{fk, fk};
+        e = vfma(xk, kk, vv); f = vfma(xk, kk, -vv);
+    }
+#ifndef GOMEL_COUNT_ONLY
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!__builtin_amdgcn_class(pk, 0x100) || !__builtin_amdgcn_class(pc, 0x100)) != 0, 0)) {
+        const v2d u = unit_phase_d(xk) * ma, vv = unit_phase_d(xc) * mb;
+        e = u + vv; f = u - vv;
+    }
+#endif
+    } else {
 #ifdef GOMEL_COUNT_ONLY   // instruction-count audits: the rare branch compiled out (never shipped)
     if (false) {
 #else
@@ -866,6 +890,7 @@ GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
         const v2d vv = xc * fc, kk = v2d{fk, fk};
         e = vfma(xk, kk, vv); f = vfma(xk, kk, -vv);       // Y[k] +- conj(Y[C-k]) with the first product riding on the multiply-adds
     }
+    }
     v2d o = cmulc(f, w), io = rot_pi(o);
     a = e + io;
     v2d t = e - io;
@@ -876,7 +901,7 @@ template <class G> GL_DEV void spectral_apply(v2d (&v)[16], int t, const MagRegs
     v2d dc = v[0];
     lane0_permute<G>(v, is0);
 #pragma unroll
-    for (int s = 0; s < 8; s++) clamp_pair_d(v[s], v[15 - s], w[s], m.ma[s], m.mb[s]);
+    for (int s = 0; s < 8; s++) clamp_pair_d<(GL_D_CLAMP_PATCH && G::N >= GL_D_CLAMP_PATCH_MINN)>(v[s], v[15 - s], w[s], m.ma[s], m.mb[s]);
     if (is0) {
         const double x0 = dc.x + dc.y, xn = dc.x - dc.y;
         const double y0 = x0 < 0.0 ? -m.m0 : m.m0, yn = xn < 0.0 ? -m.mn : m.mn;

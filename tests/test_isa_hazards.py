@@ -161,9 +161,11 @@ def test_fp64_fused_kernel_instruction_and_synchronisation_budget(isa):
     start = next(i for i, l in enumerate(isa) if l.startswith("_Z12k_gl_fused_dILi4096ELi5EE") and ":" in l)
     k = [l.strip() for l in isa[start:start + next(i for i, l in enumerate(isa[start:]) if "s_endpgm" in l) + 1]]
     hdr = next(i for i, l in enumerate(k) if "This Loop Header: Depth=1" in l)
-    latch = max(i for i, l in enumerate(k[:hdr]) if re.match(r"^\.LBB\d+_\d+:", l))
+    # the loop's blocks in front of its header (the latch: counter update, the frame's first loads) start at the first label marked as part of the loop;
+    # the first branch back to it is the common back edge -- what follows are the last frame's tail stores and the rare branches' blocks
+    latch = min(i for i, l in enumerate(k[:hdr]) if re.match(r"^\.LBB\d+_\d+:", l) and "in Loop: Header=" in l)
     label = k[latch].split(":")[0]
-    end = next(i for i in range(hdr, len(k)) if k[i].startswith("s_branch " + label))      # the back edge: what follows it are the rare branches' blocks
+    end = next(i for i in range(hdr, len(k)) if re.match(r"^s_c?branch\S* " + re.escape(label) + r"$", k[i]))
     body = list(_instructions(k[latch:end + 1]))
     ops = [b.split()[0] for b in body]
     f64 = sum("f64" in o and not o.startswith("v_rsq") and not o.startswith("v_cmp") for o in ops)
@@ -174,4 +176,6 @@ def test_fp64_fused_kernel_instruction_and_synchronisation_budget(isa):
     waits = [b for b in body if b.startswith("s_waitcnt") and "lgkmcnt" in b]
     assert sum("lgkmcnt(0)" not in w for w in waits) >= 20, len(waits)                                   # the read bursts stream into the arithmetic (counted waits)
     assert not any(o.startswith("scratch_") or o.startswith("flat_") for o in ops)
+    # branches of a frame: the eight range tests of the spectral step cost ONE each (clamp_pair_d's patch form, gl_fft.hpp GL_D_CLAMP_PATCH; the if / else form: two and a flag)
+    assert sum(o.startswith("s_cbranch") or o == "s_branch" for o in ops) <= 24, sum(o.startswith("s_cbranch") or o == "s_branch" for o in ops)
     assert sum(o.startswith("v_accvgpr") for o in ops) <= 175 and sum(o.startswith("v_mov") for o in ops) <= 110   # parking / slide traffic: keep an eye on it

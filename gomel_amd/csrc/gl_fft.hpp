@@ -847,12 +847,12 @@ GL_DEV double rsqrt_d(double p) {
 }
 // GL_D_CLAMP_PATCH: the rare scaled form of the phasor as a patch BEHIND the common form (one branch per bin pair) instead of an if / else around both (two branches
 // and a flag per pair in the compiled code: 34 scalar instructions and 8 branches more per frame).  Bit-identical; k_gl_fused_d<4096,5> -0.4 ... -0.7 % (n = 8 and 12,
-// one box each), +1.5 % at N 1024 (n = 6), the persistent kernel +-0: taken from N 4096 on.  profiles/r06/ab_clamp_patch.txt
+// one box each), -0.35 % at N 2048 / hop 256 (n = 10), +1.5 % at N 1024 (n = 6), the persistent kernel +-0: taken from N 2048 on.  profiles/r06/ab_clamp_patch.txt
 #ifndef GL_D_CLAMP_PATCH
 #define GL_D_CLAMP_PATCH 1
 #endif
 #ifndef GL_D_CLAMP_PATCH_MINN
-#define GL_D_CLAMP_PATCH_MINN 4096
+#define GL_D_CLAMP_PATCH_MINN 2048
 #endif
 template <bool PATCH> GL_DEV void clamp_pair_d(v2d& a, v2d& b, v2d w, double ma, double mb) {
     v2d bc = v2d{b.x, -b.y};

@@ -184,7 +184,7 @@ def host_to_host(engine, fields, n_local, frames, first, steps, warmup, barrier,
     L = engine.out_len(frames * K)
     blocks = [(b0, min(nb, n_local - b0)) for b0 in range(0, n_local, nb)]
     # calls in flight must not share output buffers: a second set where consecutive calls would land in the same one
-    nsets = 2 if depth >= 2 and (not whole or len(blocks) == 1) else 1
+    nsets = max(2, depth) if depth >= 2 and (not whole or len(blocks) == 1) else 1
     outs = [[alloc(L) for _ in range(nmat)] for _ in range(nsets)]
     for st in outs:
         for o in st:

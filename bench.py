@@ -629,8 +629,8 @@ def main():
             "config": {"workload": desc, "utterances_per_gpu": n_utt, "frames_per_utterance": frames, "resolut": N, "window_hop": hop,
                        "num_mels": K, "iterations": I, "parallelism": "utterance-sharded x%d" % world,
                        "precision_mode": "%s: %s" % (args.mode, MODES[args.mode][1]) + (
-                           "; held out at 60 iterations the schedule leaves about 1e-5 of utterances beyond 1e-4 RMS of float64 arithmetic (the towav geometry: 0 of 421 888, max 7.3e-5; "
-                           "the TTS geometry 5 of 376 832, worst 2.8e-4; all four calibrated geometries 7 of 1 331 200: DESIGN.md section 2) -- a rate, not a guarantee; `value_guaranteed` is fp64 throughout" if args.mode == "default" else ""),
+                           "; held out at 60 iterations the schedule leaves about 1e-5 of utterances beyond 1e-4 RMS of float64 arithmetic (the towav geometry: 1 of 684 032, worst 1.3e-4; "
+                           "the TTS geometry 18 of 901 120 = 2e-5, worst 5.6e-4; all four calibrated geometries 21 of 2 117 632: DESIGN.md section 2) -- a rate, not a guarantee; `value_guaranteed` is fp64 throughout" if args.mode == "default" else ""),
                        "fp64_iterations": engine.fp64_iterations(),
                        "default_fp64_iterations": k_default, "kernel_path": PATHS[tm["fast_path"]],
                        "timed_region": "gomel_from_mel_batch host-to-host (pinned fp64 buffers, H2D + all device work + D2H), %d utterances per call, %s" % (
